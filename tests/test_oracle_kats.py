@@ -1,0 +1,136 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own tests
+hold for the hot path: src/linalg.rs:306-446 exactly,
+src/simplex.rs:484-796 to 1e-12, and the hand trace of SURVEY Appendix B."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+
+# ------------------------------------------------------------------ src/linalg.rs KATs
+def test_lu_factorization(kats):
+    k = kats["linalg"]["lu_factorization"]
+    lu, p = ora.lu_factorize(np.array(k["a"]))
+    assert p.tolist() == k["p"]
+    assert lu.ravel().tolist() == k["lu"]  # exact: LINPACK-style unpermuted L
+
+
+def test_lu_solve(kats):
+    for k in kats["linalg"]["lu_solve"]:
+        assert ora.lu_solve(np.array(k["a"]), np.array(k["b"])).tolist() == k["x"]
+
+
+def test_matrix_roundtrip(kats):
+    a = np.array(kats["linalg"]["matrix_roundtrip"]["a"])
+    cp, ri, v = ora.csc_from_dense(a)
+    assert ora.csc_to_dense(2, 2, cp, ri, v).tolist() == a.tolist()
+
+
+def test_csc_from_dense(kats):
+    k = kats["linalg"]["csc_from_dense"]
+    cp, ri, v = ora.csc_from_dense(np.array(k["a"]))
+    assert ri.tolist() == k["row_idx"]
+    assert cp.tolist() == k["col_ptr"]
+    assert v.tolist() == k["data"]
+
+
+def test_csc_column_and_collect(kats):
+    k = kats["linalg"]["csc_column"]
+    cp, ri, v = ora.csc_from_dense(np.array(k["a"]))
+    for j, col in enumerate(k["columns"]):
+        assert ora.csc_column(3, cp, ri, v, j).tolist() == col
+    # collect_columns([1,2,0]): gathered column c equals source column cols[c];
+    # checked through neg_t_dot with unit vectors (the only consumer on the hot path)
+    cols = kats["linalg"]["csc_collect_columns"]["cols"]
+    for r in range(3):
+        e = np.zeros(3)
+        e[r] = 1.0
+        got = ora.neg_t_dot(cp, ri, v, cols, e)
+        want = [-k["columns"][c][r] for c in cols]
+        assert np.array_equal(got, np.array(want) + 0.0)
+
+
+def test_dense_transpose(kats):
+    k = kats["linalg"]["dense_transpose"]
+    assert ora.matrix_t(np.array(k["a"])).tolist() == k["t"]
+
+
+def test_neg_transpose_dot(kats):
+    k = kats["linalg"]["neg_transpose_dot"]
+    cp, ri, v = ora.csc_from_dense(np.array(k["a"]))
+    assert ora.neg_t_dot(cp, ri, v, [0, 1, 2, 3], np.array(k["v"])).tolist() == k["out"]
+
+
+# ------------------------------------------------------------------ src/simplex.rs KATs
+def _solver_ids(kats_path="tests/golden/reference_kats.json"):
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, kats_path)) as f:
+        return [k["name"] for k in json.load(f)["solver"]]
+
+
+@pytest.mark.parametrize("name", _solver_ids())
+def test_solver_kat(kats, name):
+    k = next(s for s in kats["solver"] if s["name"] == name)
+    res = ora.solve_model(k["model"], max_iter=10_000)
+    exp = k["expect"]
+    assert res.status == exp["status"]
+    if exp["status"] == "optimal":
+        assert abs(res.objective - exp["objective"]) <= 1e-12
+        for got, want in zip(res.values, exp["values"]):
+            assert abs(got - want) <= 1e-12
+
+
+# ------------------------------------------------------------------ SURVEY Appendix B
+def test_readme_lp_pivot_trace():
+    """README LP lowered as the Python surface lowers it (min x+y-z st x+y+z == 1):
+    core objective -x-y+z, rows x+y+z<=1 and -x-y-z<=-1.  Appendix B's hand trace."""
+    nn = {"lb": 0.0, "ub": None}
+    model = {
+        "vars": [nn, nn, nn],
+        "objective": {"terms": [[0, -1.0], [1, -1.0], [2, 1.0]], "constant": -0.0},
+        "constraints": [
+            {"terms": [[0, 1.0], [1, 1.0], [2, 1.0]], "b": 1.0},
+            {"terms": [[0, -1.0], [1, -1.0], [2, -1.0]], "b": -1.0},
+        ],
+    }
+    sf = ora.build_standard_form(model)
+    assert (sf.m, sf.n) == (5, 11)
+    assert sf.basis.tolist() == [6, 7, 8, 9, 10]
+    assert sf.nonbasis.tolist() == [0, 1, 2, 3, 4, 5]
+    assert sf.z.tolist() == [1.0, -1.0, 1.0, -1.0, -1.0, 1.0]
+    assert sf.x.tolist() == [1.0, -1.0, 0.0, 0.0, 0.0]
+    assert np.signbit(sf.x[2:]).all()  # -lb of a nonneg variable is -0.0
+    res = ora.simplex_solve(sf)
+    assert res.status == "optimal"
+    assert [(p[0], p[1], p[2]) for p in res.pivots] == [
+        (ora.DUAL, 4, 7), (ora.PRIMAL, 1, 8), (ora.PRIMAL, 3, 9), (ora.PRIMAL, 7, 6)]
+    assert [p[3] for p in res.pivots] == [1.0, 1.0, 1.0, 1.0]
+    assert res.basis.tolist() == [7, 4, 1, 3, 10]
+    assert res.objective == 1.0
+    vals = ora.solution_values(sf, res)
+    assert vals.tolist() == [0.0, 0.0, 1.0]
+
+
+# ------------------------------------------------------------------ IEEE corner cases
+def test_ratio_test_corner_semantics():
+    # +inf participates and wins; NaN, -inf, zero and negatives are dropped (App. A.9)
+    y = np.array([1.0, -1.0, 1.0, -1.0, -1.0, 1.0])
+    ybar = np.ones(6)
+    dy = np.array([1.0, -1.0, 1.0, -1.0, 1.0, -1.0])
+    assert ora.find_second_pivot(1.0, y, ybar, dy) == 4
+    assert ora.find_second_pivot(1.0, np.array([-1.0]), np.ones(1), np.array([0.0])) == -1
+    # first maximum wins, 0.0 and -0.0 tie (App. A.1)
+    assert ora.find_first_pivot(np.array([0.0, -0.0, 0.0]), np.ones(3)) == 0
+    assert ora.find_first_pivot(np.array([-1.0, -2.0, -2.0]), np.ones(3)) == 1
+    assert ora.find_first_pivot(np.array([-5.0, -9.0]), np.array([0.0, -1.0])) == -1
+
+
+def test_zero_pivot_column_is_skipped():
+    # src/linalg.rs:117: an all-zero pivot column leaves the matrix untouched
+    a = np.array([[0.0, 1.0], [0.0, 2.0]])
+    lu, p = ora.lu_factorize(a)
+    assert p.tolist() == [0]
+    assert lu.tolist() == a.tolist()
