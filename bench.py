@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- simplex iterations/s and pricing-kernel HBM GB/s on MI355X.
+
+Metric (BASELINE.json): simplex iterations/sec + achieved HBM GB/s on the 8192 x 16384 dense
+fp64 LP (generator G1, seed 1003).  One "step" = one executed pivot
+(status + primal/dual step).  The LP is resident in HBM before the timed region starts
+(dzg_solver_create uploads it); W warm-up pivots run first, then exactly K pivots are timed
+between barriers, continuing the same solve trajectory.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--rows M --cols NS --seed S]
+                  [--price seq|wave] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(sample_rows: int, sample_cols: int, seed: int, pivots: int, rows: int):
+    """The oracle (C restatement of the reference algorithm: full dense LU of B and of B^T
+    every iteration) timed on the host, 1 core, on a bounded sample."""
+    from dantzig_amd import core
+    from oracle import oracle as ora
+
+    a, b, c = core.gen_dense_lp(seed=seed, m=sample_rows, n_struct=sample_cols)
+    sf = ora.stdform_from_dense(a, b, c)
+    t0 = time.perf_counter()
+    res = ora.simplex_solve(sf, max_iter=pivots, log_cap=pivots)
+    dt = time.perf_counter() - t0
+    rate = res.iterations / dt if dt > 0 else float("nan")
+    scale = (sample_rows / rows) ** 3  # (4/3) m^3 flops per iteration dominate
+    return {
+        "value": rate * scale,
+        "unit": "iterations/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"first {res.iterations} pivots of the {sample_rows}x{sample_cols} G1 LP "
+                   f"(seed {seed}) on the C restatement of the reference (oracle/), "
+                   f"{dt:.1f} s of CPU; measured {rate:.3f} it/s at {sample_rows} rows, "
+                   f"value = that x ({sample_rows}/{rows})^3 (modelled from the (4/3)m^3 "
+                   f"flops/iteration of the reference's twice-per-iteration dense LU)"),
+        "measured_value": rate,
+        "measured_rows": sample_rows,
+        "host_cores_total": os.cpu_count(),
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--rows", type=int, default=8192)
+    ap.add_argument("--cols", type=int, default=16384)
+    ap.add_argument("--seed", type=int, default=1003)
+    ap.add_argument("--price", choices=["auto", "seq", "wave"], default="auto")
+    ap.add_argument("--numerics", choices=["fast", "strict"], default="fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1024)
+    ap.add_argument("--cpu-sample-pivots", type=int, default=40)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        print(f"--gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+        return 2
+    if world > 1:
+        from dantzig_amd import sharded  # column-sharded path
+
+        return sharded.bench_main(args, rank, world, local_rank)
+
+    import torch
+
+    from dantzig_amd import _ffi, core
+
+    _ffi.require_gpu()
+    torch.cuda.set_device(0)
+    t_gen = time.perf_counter()
+    a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    t_gen = time.perf_counter() - t_gen
+    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[args.price]
+    numerics = core.FAST if args.numerics == "fast" else core.STRICT
+    t_up = time.perf_counter()
+    solver = core.Solver(lp, numerics=numerics, price_kernel=price,
+                         profile=1 << _ffi.K_PRICE, poll_interval=50)
+    t_up = time.perf_counter() - t_up
+
+    status = solver.run(args.warmup) if args.warmup > 0 else "iter_limit"
+    r0 = solver.result(log=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if status == "iter_limit":
+        status = solver.run(args.steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    r1 = solver.result(log=False)
+    solver.close()
+
+    steps_done = r1.iterations - r0.iterations
+    elapsed = t1 - t0
+    price_ms = r1.kernel_ms["price"] - r0.kernel_ms["price"]
+    price_launches = r1.kernel_launches["price"] - r0.kernel_launches["price"]
+    price_bytes = r1.price_bytes - r0.price_bytes
+    achieved = (price_bytes / 1e9) / (price_ms / 1e3) if price_ms > 0 else float("nan")
+    out = {
+        "metric": "simplex_iterations_per_sec",
+        "value": steps_done / elapsed if elapsed > 0 else float("nan"),
+        "unit": "iterations/s",
+        "n_gpus": 1,
+        "steps": steps_done,
+        "warmup": r0.iterations,
+        "ms_per_step": 1e3 * elapsed / max(steps_done, 1),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"dense random LP {args.rows}x{args.cols} fp64, generator G1 seed {args.seed}",
+            "numerics": r1.numerics,
+            "price_kernel": args.price,
+            "status_after_timed_region": status,
+            "requested_steps": args.steps,
+            "lp_generation_s": round(t_gen, 3),
+            "upload_s": round(t_up, 3),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_price_seq" if args.price in ("auto", "seq") else "k_price_wave",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_us": 1e3 * price_ms / max(price_launches, 1),
+            "launches": price_launches,
+            "algorithmic_bytes_per_launch": price_bytes / max(price_launches, 1),
+        },
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, 2 * args.cpu_sample_rows, 1002,
+                                           args.cpu_sample_pivots, args.rows)
+    print(json.dumps(out))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,228 @@
+"""Host-side Python view of the Level-1 C ABI (include/dantzig_amd.h).
+
+`CoreLP` carries the state Simplex::new leaves behind (src/simplex.rs:209-223) and `Solver`
+replaces Simplex::solve (src/simplex.rs:332-343) with the HIP engine.  Everything here is
+plumbing over ctypes; the arithmetic lives in dantzig_amd/csrc/*.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (AUTO, FAST, STRICT, PRICE_AUTO, PRICE_SEQ, PRICE_WAVE, STEP_DUAL,  # noqa: F401
+                   STEP_PRIMAL, DantzigAmdError, f64, i64, ptr)
+
+STATUS_NAMES = {0: "optimal", 1: "unbounded", 2: "infeasible", 3: "iter_limit", 4: "singular",
+                5: "panic", 6: "running"}
+
+
+@dataclass
+class CoreLP:
+    """maximise c.x + constant  s.t.  [A | slacks] x = rhs, x >= 0, in Simplex::new's layout."""
+    a: np.ndarray                 # (m, n_struct) any layout; uploaded column-major
+    c: np.ndarray                 # n
+    basis: np.ndarray             # m
+    nonbasis: np.ndarray          # n - m
+    x: np.ndarray                 # m
+    z: np.ndarray                 # n - m
+    var_col: np.ndarray | None = None
+    constant: float = 0.0
+
+    @property
+    def m(self) -> int:
+        return int(self.a.shape[0])
+
+    @property
+    def n_struct(self) -> int:
+        return int(self.a.shape[1])
+
+    @property
+    def n(self) -> int:
+        return len(self.c)
+
+    @classmethod
+    def from_inequality_form(cls, a, b, c, constant: float = 0.0) -> "CoreLP":
+        """max c.x st A x <= b, x >= 0 in the benchmark convention of SURVEY 8(d): variables
+        0..ns-1 structural, ns..ns+m-1 slacks, slack basis, x = b, z = -c."""
+        a = np.asarray(a, dtype=np.float64)
+        m, ns = a.shape
+        return cls(a=a, c=np.concatenate([f64(c), np.zeros(m)]),
+                   basis=np.arange(ns, ns + m, dtype=np.int64),
+                   nonbasis=np.arange(ns, dtype=np.int64), x=f64(b).copy(), z=-f64(c),
+                   var_col=None, constant=constant)
+
+
+@dataclass
+class CoreResult:
+    status: str
+    status_code: int
+    numerics: str
+    iterations: int
+    objective: float
+    basis: np.ndarray
+    nonbasis: np.ndarray
+    x: np.ndarray
+    xbar: np.ndarray
+    z: np.ndarray
+    zbar: np.ndarray
+    pivots: list = field(default_factory=list)   # (kind, entering, leaving, mu)
+    kernel_ms: dict = field(default_factory=dict)
+    kernel_launches: dict = field(default_factory=dict)
+    price_bytes: float = 0.0
+    solve_ms: float = 0.0
+
+
+class Solver:
+    """One LP resident on one GPU.  create -> run (repeatable, budgeted) -> result."""
+
+    def __init__(self, lp: CoreLP, **opts):
+        _ffi.require_gpu()
+        self._lp = lp
+        m, ns, n = lp.m, lp.n_struct, lp.n
+        # column-major m x ns == C-contiguous (ns, m)
+        a_cm = np.ascontiguousarray(np.asarray(lp.a, dtype=np.float64).T)
+        self._keep = dict(a=a_cm, c=f64(lp.c), basis=i64(lp.basis), nonbasis=i64(lp.nonbasis),
+                          x=f64(lp.x), z=f64(lp.z),
+                          var_col=None if lp.var_col is None else i64(lp.var_col))
+        k = self._keep
+        if len(k["basis"]) != m or len(k["x"]) != m or len(k["nonbasis"]) != n - m \
+                or len(k["z"]) != n - m:
+            raise ValueError("CoreLP vectors do not match (m, n)")
+        self._c_lp = _ffi.Lp(m, n, ns, ptr(a_cm), max(m, 1), ptr(k["var_col"]), ptr(k["c"]),
+                             float(lp.constant), ptr(k["basis"]), ptr(k["nonbasis"]),
+                             ptr(k["x"]), ptr(k["z"]))
+        self._opts = _ffi.default_opts(**opts)
+        self._h = C.c_void_p(None)
+        rc = _ffi.lib().dzg_solver_create(C.byref(self._c_lp), C.byref(self._opts),
+                                          C.byref(self._h))
+        _ffi.check(rc, "dzg_solver_create")
+
+    def run(self, max_new_iters: int = 0) -> str:
+        rc = _ffi.lib().dzg_solver_run(self._h, int(max_new_iters))
+        _ffi.check(rc, "dzg_solver_run")
+        return STATUS_NAMES[rc]
+
+    def result(self, log: bool = True, log_cap: int | None = None) -> CoreResult:
+        m, q = self._lp.m, self._lp.n - self._lp.m
+        basis, nonbasis = np.zeros(max(m, 1), np.int64), np.zeros(max(q, 1), np.int64)
+        x, xbar = np.zeros(max(m, 1)), np.zeros(max(m, 1))
+        z, zbar = np.zeros(max(q, 1)), np.zeros(max(q, 1))
+        cap = int(log_cap if log_cap is not None else (1 << 22)) if log else 0
+        # first learn the iteration count so the log buffer is not oversized
+        r = _ffi.Result()
+        r.basis, r.nonbasis, r.x, r.xbar = ptr(basis), ptr(nonbasis), ptr(x), ptr(xbar)
+        r.z, r.zbar = ptr(z), ptr(zbar)
+        r.log, r.log_cap = None, 0
+        _ffi.check(_ffi.lib().dzg_solver_result(self._h, C.byref(r)), "dzg_solver_result")
+        pivots = []
+        if log and r.iterations > 0:
+            cnt = int(min(r.iterations, cap))
+            buf = (_ffi.Pivot * cnt)()
+            r.log, r.log_cap = C.cast(buf, C.c_void_p), cnt
+            _ffi.check(_ffi.lib().dzg_solver_result(self._h, C.byref(r)), "dzg_solver_result")
+            arr = np.ctypeslib.as_array(buf)
+            pivots = list(zip(arr["kind"].tolist(), arr["entering"].tolist(),
+                              arr["leaving"].tolist(), arr["mu"].tolist()))
+        return CoreResult(
+            status=STATUS_NAMES.get(r.status, str(r.status)), status_code=r.status,
+            numerics="strict" if r.numerics_used == STRICT else "fast",
+            iterations=int(r.iterations), objective=float(r.objective),
+            basis=basis[:m].copy(), nonbasis=nonbasis[:q].copy(), x=x[:m].copy(),
+            xbar=xbar[:m].copy(), z=z[:q].copy(), zbar=zbar[:q].copy(), pivots=pivots,
+            kernel_ms={k: r.kernel_ms[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
+            kernel_launches={k: r.kernel_launches[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
+            price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms))
+
+    def close(self) -> None:
+        if self._h:
+            _ffi.lib().dzg_solver_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve(lp: CoreLP, log: bool = True, **opts) -> CoreResult:
+    """Simplex::solve on the GPU: create + run to termination + result."""
+    with Solver(lp, **opts) as s:
+        s.run(0)
+        return s.result(log=log)
+
+
+# ------------------------------------------------------------------ synthetic LPs
+def gen_dense_lp(seed: int, m: int, n_struct: int):
+    """Generator G1.  Returns (A as an (m, n_struct) Fortran-ordered array, b, c)."""
+    a = np.empty((n_struct, m), dtype=np.float64)  # C-contiguous (ns, m) == column-major m x ns
+    b = np.empty(m)
+    c = np.empty(n_struct)
+    rc = _ffi.lib().dzg_gen_dense_lp(C.c_uint64(seed), m, n_struct, ptr(a), m, ptr(b), ptr(c))
+    _ffi.check(rc, "dzg_gen_dense_lp")
+    return a.T, b, c
+
+
+# ------------------------------------------------------------------ single reference functions
+def lu_solve(a: np.ndarray, b: np.ndarray, device: int = 0):
+    """lu_solve (src/linalg.rs:8-10) on the GPU.  Returns (x, packed LU, pivots)."""
+    _ffi.require_gpu()
+    a, b = f64(a), f64(b)
+    n = a.shape[0]
+    x, lu, p = np.empty(n), np.empty((n, n)), np.zeros(max(n - 1, 1), np.int64)
+    rc = _ffi.lib().dzg_kernel_lu_solve(C.c_int64(n), ptr(a), ptr(b), ptr(x), ptr(lu), ptr(p),
+                                        C.c_int32(device))
+    _ffi.check(rc, "dzg_kernel_lu_solve")
+    return x, lu, p[: n - 1]
+
+
+def neg_t_dot(a: np.ndarray, cols, v, kernel: int = PRICE_SEQ, device: int = 0) -> np.ndarray:
+    """collect_columns(cols).neg_t_dot(v) (src/linalg.rs:188-207) on the GPU, a is (m, ns)."""
+    _ffi.require_gpu()
+    a = np.asarray(a, dtype=np.float64)
+    m, ns = a.shape
+    a_cm = np.ascontiguousarray(a.T)
+    cols, v = i64(cols), f64(v)
+    out = np.empty(max(len(cols), 1))
+    rc = _ffi.lib().dzg_kernel_neg_t_dot(C.c_int64(m), C.c_int64(ns), ptr(a_cm), C.c_int64(m),
+                                         ptr(cols), C.c_int64(len(cols)), ptr(v), ptr(out),
+                                         C.c_int32(kernel), C.c_int32(device))
+    _ffi.check(rc, "dzg_kernel_neg_t_dot")
+    return out[: len(cols)]
+
+
+def first_pivot(y, ybar, device: int = 0) -> int:
+    _ffi.require_gpu()
+    y, ybar = f64(y), f64(ybar)
+    out = C.c_int64(-1)
+    rc = _ffi.lib().dzg_kernel_first_pivot(C.c_int64(len(y)), ptr(y), ptr(ybar), C.byref(out),
+                                           C.c_int32(device))
+    _ffi.check(rc, "dzg_kernel_first_pivot")
+    return int(out.value)
+
+
+def second_pivot(mu, y, ybar, dy, device: int = 0) -> int:
+    _ffi.require_gpu()
+    y, ybar, dy = f64(y), f64(ybar), f64(dy)
+    out = C.c_int64(-1)
+    rc = _ffi.lib().dzg_kernel_second_pivot(C.c_int64(len(y)), C.c_double(mu), ptr(y), ptr(ybar),
+                                            ptr(dy), C.byref(out), C.c_int32(device))
+    _ffi.check(rc, "dzg_kernel_second_pivot")
+    return int(out.value)
+
+
+def merge_candidates(cands) -> int:
+    """cands: iterable of (ratio, pos, y, ybar, dy); pos < 0 means empty."""
+    arr = (_ffi.Candidate * max(len(cands), 1))()
+    for i, (r, p, y, yb, dy) in enumerate(cands):
+        arr[i] = _ffi.Candidate(r, p if p >= 0 else (1 << 63) - 1, y, yb, dy)
+    return int(_ffi.lib().dzg_merge_candidates(arr, C.c_int64(len(cands))))

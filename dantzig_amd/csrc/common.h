@@ -1,0 +1,164 @@
+// common.h -- shared declarations of the gfx950 simplex engine (device + host).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dantzig_amd.h"
+
+#define DZG_WAVE 64
+
+// ---------------------------------------------------------------------------------
+// Device-resident control block.  Every per-iteration decision (primal or dual step,
+// entering / leaving position, step lengths, termination) is taken on the device and
+// read by the following kernels from here, so the host can enqueue iterations blindly
+// and only polls `status` every few dozen iterations (no per-pivot host round trip).
+// ---------------------------------------------------------------------------------
+struct DzgCtl {
+    int status;          // dzg_status; kernels are no-ops unless DZG_RUNNING
+    int kind;            // dzg_step_kind of the iteration in flight
+    long long iter;      // executed pivots
+    long long iter_stop; // run budget: status := ITER_LIMIT once iter reaches it
+    int enter_pos;       // position in nonbasis[] of the entering variable
+    int leave_pos;       // position in basis[] of the leaving variable
+    int enter_var;       // variable indices of the pivot just executed (set by k_prepare)
+    int leave_var;
+    double mu;
+    double t, s, tbar, sbar; // step lengths (src/simplex.rs:257-260)
+    long long nb_struct; // nonbasic structural columns right now ("s" of SURVEY 8(d))
+    double price_bytes;  // algorithmic pricing bytes, accumulated per executed pivot
+    // strict LU step scratch
+    int lu_mu;
+    int lu_pivot_zero;
+    // fast numerics health
+    double max_growth;
+    int pad0, pad1;
+};
+
+// argmax candidate: k < 0 means "none"
+struct DzgCand {
+    double r;
+    int k;
+};
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ DzgCand dzg_better(DzgCand a, DzgCand b)
+{
+    // Largest ratio wins; on equal ratios the LOWER position wins.  This is the parallel
+    // form of the reference's sequential "replace only if ratio > best" scan
+    // (src/simplex.rs:432-435, :456-459); 0.0 and -0.0 compare equal, as there.
+    if (b.k < 0) return a;
+    if (a.k < 0) return b;
+    if (b.r > a.r || (b.r == a.r && b.k < a.k)) return b;
+    return a;
+}
+
+__device__ __forceinline__ DzgCand dzg_wave_best(DzgCand c)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        DzgCand o;
+        o.r = __shfl_xor(c.r, off, DZG_WAVE);
+        o.k = __shfl_xor(c.k, off, DZG_WAVE);
+        c = dzg_better(c, o);
+    }
+    return c;
+}
+
+// Block-wide reduction; result valid in every thread.  blockDim.x <= 1024.
+__device__ __forceinline__ DzgCand dzg_block_best(DzgCand c)
+{
+    __shared__ double s_r[16];
+    __shared__ int s_k[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    c = dzg_wave_best(c);
+    __syncthreads(); // protect s_r/s_k from a previous use
+    if (lane == 0) {
+        s_r[wave] = c.r;
+        s_k[wave] = c.k;
+    }
+    __syncthreads();
+    DzgCand o;
+    o.r = (lane < nw) ? s_r[lane] : 0.0;
+    o.k = (lane < nw) ? s_k[lane] : -1;
+    o = dzg_wave_best(o);
+    return o;
+}
+
+// x / y with 0 / 0 = 0 (src/simplex.rs:464-468); *ok cleared on a non-finite result.
+__device__ __forceinline__ double dzg_safe_divide(double x, double y, int *ok)
+{
+    double d = (x == 0.0 && y == 0.0) ? 0.0 : x / y;
+    if (isinf(d) || isnan(d)) *ok = 0;
+    return d;
+}
+
+__device__ __forceinline__ double dzg_readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+#endif // __HIPCC__
+
+// ---------------------------------------------------------------------------------
+// Host-side launch wrappers (defined in the .hip files, called by engine.hip).
+// All take the stream; all kernels early-out unless ctl->status == DZG_RUNNING.
+// ---------------------------------------------------------------------------------
+struct DzgDev {
+    // problem
+    int m, q, n, ns;
+    long long lda;
+    const double *A;   // column-major m x ns, lda
+    const int *var_col; // n
+    // state
+    int *basis, *nonbasis; // m, q
+    double *x, *xbar, *z, *zbar; // m, m, q, q
+    double *dx, *dz, *v, *acol, *w; // m, q, m, m, m
+    DzgCtl *ctl;
+    // log
+    int *log_kind, *log_enter, *log_leave;
+    double *log_mu;
+    long long log_cap;
+    // fast numerics
+    double *binv; // m x m row-major
+    // strict numerics
+    double *lu;   // m x m row-major workspace
+    double *lt;   // m x m: multipliers, column k contiguous
+    int *piv;     // m
+    double *urow, *krow, *lcol; // m each
+    double eps;
+};
+
+// k_vector.hip
+void dzg_launch_status(const DzgDev &d, hipStream_t st);
+void dzg_launch_ratio(const DzgDev &d, int need_kind, hipStream_t st);
+void dzg_launch_prepare(const DzgDev &d, hipStream_t st);
+void dzg_launch_update_vectors(const DzgDev &d, hipStream_t st);
+void dzg_launch_load_column(const DzgDev &d, int need_kind, hipStream_t st);
+void dzg_launch_unit_rhs(const DzgDev &d, hipStream_t st);
+int dzg_run_first_pivot(int64_t len, const double *y, const double *ybar, int64_t *pos_out);
+int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *ybar,
+                         const double *dy, int64_t *pos_out);
+
+// k_price.hip
+void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
+void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
+                          int ncols, const double *v, double *out, hipStream_t st);
+
+// k_strict.hip
+// solves  B y = rhs  (transposed == 0, rhs = d.acol -> d.dx)  or
+//         B^T y = rhs (transposed == 1, rhs = unit(leave_pos) -> d.v)
+// with the reference's dense LU; `need_kind` < 0 runs unconditionally.
+void dzg_launch_strict_solve(const DzgDev &d, int transposed, hipStream_t st);
+void dzg_launch_lu_raw(int n, double *lu, double *lt, int *piv, double *urow, double *krow,
+                       double *lcol, DzgCtl *ctl, double *b, hipStream_t st);
+
+// k_fast.hip
+void dzg_launch_fast_init(const DzgDev &d, hipStream_t st);
+void dzg_launch_fast_ftran(const DzgDev &d, int need_kind, hipStream_t st);
+void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st);
+void dzg_launch_fast_update(const DzgDev &d, hipStream_t st);

@@ -1,0 +1,612 @@
+// engine.hip -- host orchestration of the simplex iteration and the Level-1 C ABI.
+//
+// Replaces Simplex::solve (src/simplex.rs:332-343).  The reference recurses once per
+// pivot on one CPU thread; here the host only enqueues kernels on one HIP stream.  All
+// decisions live in the device control block (DzgCtl), so in FAST numerics the host
+// enqueues `poll_interval` iterations back to back and reads the status word once per
+// batch.  STRICT numerics needs O(m) launches per iteration anyway and reads the step kind
+// after the status kernel to launch only the solves that iteration uses.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_OK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(DZG_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int dzg_abi_version(void) { return DZG_ABI_VERSION; }
+
+extern "C" const char *dzg_last_error(void) { return g_err.c_str(); }
+
+extern "C" const char *dzg_status_str(int s)
+{
+    switch (s) {
+    case DZG_OPTIMAL: return "optimal";
+    case DZG_UNBOUNDED: return "unbounded";
+    case DZG_INFEASIBLE: return "infeasible";
+    case DZG_ITER_LIMIT: return "iter_limit";
+    case DZG_SINGULAR: return "singular";
+    case DZG_PANIC: return "panic";
+    case DZG_RUNNING: return "running";
+    case DZG_E_DEVICE: return "device_error";
+    case DZG_E_ARG: return "bad_argument";
+    case DZG_E_NOMEM: return "out_of_memory";
+    default: return "unknown";
+    }
+}
+
+extern "C" int dzg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void dzg_opts_default(dzg_opts *o)
+{
+    std::memset(o, 0, sizeof(*o));
+    o->numerics = DZG_NUMERICS_AUTO;
+    o->price_kernel = DZG_PRICE_AUTO;
+    o->device = 0;
+    o->auto_strict_rows = 192;
+    o->max_iter = 10000000;
+    o->epsilon = 1e-12;
+    o->log_capacity = -1;
+    o->poll_interval = 32;
+    o->profile = 0;
+    o->world = 1;
+}
+
+struct dzg_solver {
+    DzgDev d{};
+    dzg_opts opts{};
+    int numerics = DZG_NUMERICS_FAST;
+    hipStream_t st = nullptr;
+    DzgCtl *h_ctl = nullptr; // pinned
+    std::vector<void *> allocs;
+    std::vector<double> c_host;
+    double constant = 0.0;
+    double solve_ms = 0.0;
+    long long iter_known = 0;
+    int status_known = DZG_RUNNING;
+    // profiling
+    std::vector<hipEvent_t> ev; // [batch slot][class][2]
+    double kernel_ms[DZG_K_COUNT] = {};
+    int64_t kernel_launches[DZG_K_COUNT] = {};
+};
+
+template <typename T> static int dev_alloc(dzg_solver *s, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = sizeof(T) * (count ? count : 1);
+    if (hipMalloc(&q, bytes) != hipSuccess)
+        return fail(DZG_E_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    s->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return 0;
+}
+
+#define TRY(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+static int validate(const dzg_lp *lp, std::string &why)
+{
+    if (!lp) { why = "lp is NULL"; return 0; }
+    if (lp->m < 0 || lp->n < lp->m || lp->n_struct < 0 || lp->n_struct > lp->n) { why = "bad sizes"; return 0; }
+    if (lp->n >= (1ll << 31) - 64 || lp->m >= (1ll << 31) - 64) { why = "index range"; return 0; }
+    if (lp->n_struct > 0 && (!lp->a || lp->lda < lp->m)) { why = "a / lda"; return 0; }
+    const int64_t q = lp->n - lp->m;
+    if ((lp->m > 0 && (!lp->basis || !lp->x)) || (q > 0 && (!lp->nonbasis || !lp->z)) || (lp->n > 0 && !lp->c)) { why = "NULL state vector"; return 0; }
+    if (!lp->var_col && lp->n != lp->n_struct + lp->m) { why = "var_col == NULL needs n == n_struct + m"; return 0; }
+    std::vector<char> seen((size_t)lp->n, 0);
+    for (int64_t k = 0; k < lp->n; ++k) {
+        int64_t v = k < lp->m ? lp->basis[k] : lp->nonbasis[k - lp->m];
+        if (v < 0 || v >= lp->n || seen[(size_t)v]) { why = "basis/nonbasis is not a partition of 0..n-1"; return 0; }
+        seen[(size_t)v] = 1;
+    }
+    if (lp->var_col) {
+        for (int64_t v = 0; v < lp->n; ++v) {
+            int64_t c = lp->var_col[v];
+            if (c >= lp->n_struct || c < -lp->m) { why = "var_col out of range"; return 0; }
+        }
+    }
+    return 1;
+}
+
+extern "C" void dzg_solver_destroy(dzg_solver *s)
+{
+    if (!s) return;
+    for (hipEvent_t e : s->ev) hipEventDestroy(e);
+    for (void *p : s->allocs) hipFree(p);
+    if (s->h_ctl) hipHostFree(s->h_ctl);
+    if (s->st) hipStreamDestroy(s->st);
+    delete s;
+}
+
+extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_solver **out)
+{
+    if (!out) return fail(DZG_E_ARG, "out is NULL");
+    *out = nullptr;
+    std::string why;
+    if (!validate(lp, why)) return fail(DZG_E_ARG, "invalid dzg_lp: " + why);
+    dzg_opts o;
+    if (opts_in) o = *opts_in; else dzg_opts_default(&o);
+    if (o.max_iter <= 0) o.max_iter = 10000000;
+    if (o.poll_interval <= 0) o.poll_interval = 32;
+    if (o.epsilon == 0.0) o.epsilon = 1e-12;
+    if (o.auto_strict_rows <= 0) o.auto_strict_rows = 192;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DZG_E_DEVICE, "no HIP device visible: dantzig_amd has no CPU path");
+    if (o.device < 0 || o.device >= ndev) return fail(DZG_E_ARG, "opts.device out of range");
+    HIP_OK(hipSetDevice(o.device));
+
+    dzg_solver *s = new dzg_solver();
+    s->opts = o;
+    struct Guard { dzg_solver *s; ~Guard() { if (s) dzg_solver_destroy(s); } } guard{s};
+    HIP_OK(hipStreamCreate(&s->st));
+    HIP_OK(hipHostMalloc((void **)&s->h_ctl, sizeof(DzgCtl)));
+
+    DzgDev &d = s->d;
+    const int m = (int)lp->m, n = (int)lp->n, ns = (int)lp->n_struct, q = n - m;
+    d.m = m; d.n = n; d.ns = ns; d.q = q;
+    d.lda = ((long long)m + 15) / 16 * 16;
+    if (d.lda == 0) d.lda = 16;
+    d.eps = o.epsilon;
+
+    // --- constraint matrix: column-major, zero-padded to lda rows (16-B aligned columns)
+    double *A = nullptr;
+    TRY(dev_alloc(s, &A, (size_t)d.lda * (size_t)(ns ? ns : 1)));
+    HIP_OK(hipMemsetAsync(A, 0, sizeof(double) * (size_t)d.lda * (size_t)(ns ? ns : 1), s->st));
+    if (ns > 0 && m > 0) {
+        // the reference's CSC drops exact zeros (src/linalg.rs:261), so -0.0 entries act as +0.0
+        bool has_negzero = false;
+        for (int64_t j = 0; j < ns && !has_negzero; ++j)
+            for (int64_t i = 0; i < m; ++i) {
+                const double val = lp->a[j * lp->lda + i];
+                if (val == 0.0 && std::signbit(val)) { has_negzero = true; break; }
+            }
+        if (!has_negzero) {
+            HIP_OK(hipMemcpy2DAsync(A, sizeof(double) * d.lda, lp->a, sizeof(double) * lp->lda,
+                                    sizeof(double) * m, ns, hipMemcpyHostToDevice, s->st));
+        } else {
+            std::vector<double> tmp((size_t)m * ns);
+            for (int64_t j = 0; j < ns; ++j)
+                for (int64_t i = 0; i < m; ++i) {
+                    const double val = lp->a[j * lp->lda + i];
+                    tmp[(size_t)(j * m + i)] = (val == 0.0) ? 0.0 : val;
+                }
+            HIP_OK(hipMemcpy2DAsync(A, sizeof(double) * d.lda, tmp.data(), sizeof(double) * m,
+                                    sizeof(double) * m, ns, hipMemcpyHostToDevice, s->st));
+            HIP_OK(hipStreamSynchronize(s->st));
+        }
+    }
+    d.A = A;
+
+    // --- index maps
+    std::vector<int> var_col((size_t)(n ? n : 1));
+    for (int v = 0; v < n; ++v)
+        var_col[v] = lp->var_col ? (int)lp->var_col[v] : (v < ns ? v : -1 - (v - ns));
+    std::vector<int> basis((size_t)(m ? m : 1)), nonbasis((size_t)(q ? q : 1));
+    long long nb_struct = 0;
+    for (int p = 0; p < m; ++p) basis[p] = (int)lp->basis[p];
+    for (int k = 0; k < q; ++k) {
+        nonbasis[k] = (int)lp->nonbasis[k];
+        if (var_col[nonbasis[k]] >= 0) ++nb_struct;
+    }
+    int *d_var_col, *d_basis, *d_nonbasis;
+    TRY(dev_alloc(s, &d_var_col, (size_t)n));
+    TRY(dev_alloc(s, &d_basis, (size_t)m));
+    TRY(dev_alloc(s, &d_nonbasis, (size_t)q));
+    HIP_OK(hipMemcpyAsync(d_var_col, var_col.data(), sizeof(int) * (size_t)(n ? n : 1), hipMemcpyHostToDevice, s->st));
+    HIP_OK(hipMemcpyAsync(d_basis, basis.data(), sizeof(int) * (size_t)(m ? m : 1), hipMemcpyHostToDevice, s->st));
+    HIP_OK(hipMemcpyAsync(d_nonbasis, nonbasis.data(), sizeof(int) * (size_t)(q ? q : 1), hipMemcpyHostToDevice, s->st));
+    d.var_col = d_var_col; d.basis = d_basis; d.nonbasis = d_nonbasis;
+
+    // --- state vectors: x = rhs, z = -c_N, xbar = zbar = 1 (src/simplex.rs:190-205)
+    TRY(dev_alloc(s, &d.x, (size_t)m)); TRY(dev_alloc(s, &d.xbar, (size_t)m));
+    TRY(dev_alloc(s, &d.z, (size_t)q)); TRY(dev_alloc(s, &d.zbar, (size_t)q));
+    TRY(dev_alloc(s, &d.dx, (size_t)m)); TRY(dev_alloc(s, &d.dz, (size_t)q));
+    TRY(dev_alloc(s, &d.v, (size_t)m + 2)); TRY(dev_alloc(s, &d.acol, (size_t)m));
+    TRY(dev_alloc(s, &d.w, (size_t)m + 2));
+    std::vector<double> ones((size_t)((m > q ? m : q) + 1), 1.0);
+    if (m > 0) {
+        HIP_OK(hipMemcpyAsync(d.x, lp->x, sizeof(double) * m, hipMemcpyHostToDevice, s->st));
+        HIP_OK(hipMemcpyAsync(d.xbar, ones.data(), sizeof(double) * m, hipMemcpyHostToDevice, s->st));
+    }
+    if (q > 0) {
+        HIP_OK(hipMemcpyAsync(d.z, lp->z, sizeof(double) * q, hipMemcpyHostToDevice, s->st));
+        HIP_OK(hipMemcpyAsync(d.zbar, ones.data(), sizeof(double) * q, hipMemcpyHostToDevice, s->st));
+    }
+    HIP_OK(hipMemsetAsync(d.v, 0, sizeof(double) * ((size_t)m + 2), s->st));
+    HIP_OK(hipMemsetAsync(d.w, 0, sizeof(double) * ((size_t)m + 2), s->st));
+    s->c_host.assign(lp->c, lp->c + n);
+    s->constant = lp->constant;
+
+    // --- pivot log
+    long long cap = o.log_capacity >= 0 ? o.log_capacity : (o.max_iter < (1ll << 22) ? o.max_iter : (1ll << 22));
+    d.log_cap = cap;
+    TRY(dev_alloc(s, &d.log_kind, (size_t)cap)); TRY(dev_alloc(s, &d.log_enter, (size_t)cap));
+    TRY(dev_alloc(s, &d.log_leave, (size_t)cap)); TRY(dev_alloc(s, &d.log_mu, (size_t)cap));
+
+    // --- numerics
+    s->numerics = o.numerics == DZG_NUMERICS_AUTO
+                      ? (m <= o.auto_strict_rows ? DZG_NUMERICS_STRICT : DZG_NUMERICS_FAST)
+                      : o.numerics;
+    if (s->numerics != DZG_NUMERICS_STRICT && s->numerics != DZG_NUMERICS_FAST)
+        return fail(DZG_E_ARG, "opts.numerics");
+    TRY(dev_alloc(s, &d.ctl, 1));
+    DzgCtl c0;
+    std::memset(&c0, 0, sizeof(c0));
+    c0.status = DZG_RUNNING;
+    c0.iter_stop = o.max_iter;
+    c0.enter_pos = c0.leave_pos = -1;
+    c0.nb_struct = nb_struct;
+    HIP_OK(hipMemcpyAsync(d.ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, s->st));
+    *s->h_ctl = c0;
+
+    if (s->numerics == DZG_NUMERICS_FAST) {
+        std::vector<char> row_seen((size_t)(m ? m : 1), 0);
+        for (int p = 0; p < m; ++p) {
+            const int code = var_col[basis[p]];
+            if (code >= 0 || row_seen[(size_t)(-1 - code)])
+                return fail(DZG_E_ARG, "FAST numerics starts from the slack basis (as Simplex::new "
+                                       "builds it); use STRICT for an arbitrary starting basis");
+            row_seen[(size_t)(-1 - code)] = 1;
+        }
+        TRY(dev_alloc(s, &d.binv, (size_t)m * (size_t)m));
+        dzg_launch_fast_init(d, s->st);
+    } else {
+        TRY(dev_alloc(s, &d.lu, (size_t)m * (size_t)m));
+        TRY(dev_alloc(s, &d.lt, (size_t)m * (size_t)m));
+        TRY(dev_alloc(s, &d.piv, (size_t)m));
+        TRY(dev_alloc(s, &d.urow, (size_t)m)); TRY(dev_alloc(s, &d.krow, (size_t)m));
+        TRY(dev_alloc(s, &d.lcol, (size_t)m));
+    }
+    if (o.profile) {
+        s->ev.resize((size_t)o.poll_interval * DZG_K_COUNT * 2);
+        for (auto &e : s->ev) HIP_OK(hipEventCreate(&e));
+    }
+    HIP_OK(hipStreamSynchronize(s->st));
+    HIP_OK(hipGetLastError());
+    guard.s = nullptr;
+    *out = s;
+    return 0;
+}
+
+// ---- one iteration, enqueued ------------------------------------------------------
+namespace {
+struct Prof {
+    dzg_solver *s;
+    int slot;
+    void begin(int cls) const
+    {
+        if (s->opts.profile & (1 << cls))
+            hipEventRecord(s->ev[((size_t)slot * DZG_K_COUNT + cls) * 2], s->st);
+    }
+    void end(int cls) const
+    {
+        if (s->opts.profile & (1 << cls))
+            hipEventRecord(s->ev[((size_t)slot * DZG_K_COUNT + cls) * 2 + 1], s->st);
+    }
+};
+} // namespace
+
+static int price_kernel_for(const dzg_solver *s)
+{
+    return s->opts.price_kernel == DZG_PRICE_AUTO ? DZG_PRICE_SEQ : s->opts.price_kernel;
+}
+
+static void enqueue_fast_iteration(dzg_solver *s, int slot)
+{
+    const DzgDev &d = s->d;
+    hipStream_t st = s->st;
+    Prof pf{s, slot};
+    pf.begin(DZG_K_STATUS);
+    dzg_launch_status(d, st);
+    pf.end(DZG_K_STATUS);
+    pf.begin(DZG_K_FTRAN);
+    dzg_launch_fast_ftran(d, DZG_STEP_PRIMAL, st); // primal step: dx first
+    pf.end(DZG_K_FTRAN);
+    pf.begin(DZG_K_RATIO);
+    dzg_launch_ratio(d, DZG_STEP_PRIMAL, st);
+    pf.end(DZG_K_RATIO);
+    pf.begin(DZG_K_BTRAN);
+    dzg_launch_fast_btran(d, st);
+    pf.end(DZG_K_BTRAN);
+    pf.begin(DZG_K_PRICE);
+    dzg_launch_price(d, price_kernel_for(s), st);
+    pf.end(DZG_K_PRICE);
+    dzg_launch_ratio(d, DZG_STEP_DUAL, st);
+    dzg_launch_fast_ftran(d, DZG_STEP_DUAL, st); // dual step: dx last
+    pf.begin(DZG_K_UPDATE);
+    dzg_launch_prepare(d, st);
+    dzg_launch_update_vectors(d, st);
+    pf.end(DZG_K_UPDATE);
+    pf.begin(DZG_K_BASIS_UPDATE);
+    dzg_launch_fast_update(d, st);
+    pf.end(DZG_K_BASIS_UPDATE);
+}
+
+static void collect_profile(dzg_solver *s, int slots_real)
+{
+    if (!s->opts.profile) return;
+    for (int slot = 0; slot < slots_real; ++slot)
+        for (int cls = 0; cls < DZG_K_COUNT; ++cls) {
+            if (!(s->opts.profile & (1 << cls))) continue;
+            float ms = 0.f;
+            size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
+            if (hipEventElapsedTime(&ms, s->ev[base], s->ev[base + 1]) == hipSuccess) {
+                s->kernel_ms[cls] += ms;
+                s->kernel_launches[cls] += 1;
+            }
+        }
+}
+
+static int read_ctl(dzg_solver *s)
+{
+    HIP_OK(hipMemcpyAsync(s->h_ctl, s->d.ctl, sizeof(DzgCtl), hipMemcpyDeviceToHost, s->st));
+    HIP_OK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
+static int run_fast(dzg_solver *s)
+{
+    const int poll = s->opts.poll_interval;
+    for (;;) {
+        const long long before = s->h_ctl->iter;
+        long long remaining = s->h_ctl->iter_stop - before;
+        int batch = (int)(remaining < poll ? (remaining < 1 ? 1 : remaining) : poll);
+        for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
+        TRY(read_ctl(s));
+        HIP_OK(hipGetLastError());
+        collect_profile(s, (int)(s->h_ctl->iter - before));
+        if (s->h_ctl->status != DZG_RUNNING) break;
+    }
+    return 0;
+}
+
+static int run_strict(dzg_solver *s)
+{
+    const DzgDev &d = s->d;
+    hipStream_t st = s->st;
+    for (;;) {
+        dzg_launch_status(d, st);
+        TRY(read_ctl(s));
+        if (s->h_ctl->status != DZG_RUNNING) break;
+        if (s->h_ctl->kind == DZG_STEP_PRIMAL) { // src/simplex.rs:308-318
+            dzg_launch_load_column(d, -1, st);
+            hipMemcpyAsync(d.dx, d.acol, sizeof(double) * (size_t)d.m, hipMemcpyDeviceToDevice, st);
+            dzg_launch_strict_solve(d, 0, st);
+            dzg_launch_ratio(d, DZG_STEP_PRIMAL, st);
+            dzg_launch_unit_rhs(d, st); // needs leave_pos: no-op if the ratio test found none
+            dzg_launch_strict_solve(d, 1, st);
+            dzg_launch_price(d, DZG_PRICE_SEQ, st);
+        } else { // :320-330
+            dzg_launch_unit_rhs(d, st);
+            dzg_launch_strict_solve(d, 1, st);
+            dzg_launch_price(d, DZG_PRICE_SEQ, st);
+            dzg_launch_ratio(d, DZG_STEP_DUAL, st);
+            dzg_launch_load_column(d, -1, st);
+            hipMemcpyAsync(d.dx, d.acol, sizeof(double) * (size_t)d.m, hipMemcpyDeviceToDevice, st);
+            dzg_launch_strict_solve(d, 0, st);
+        }
+        dzg_launch_prepare(d, st);
+        dzg_launch_update_vectors(d, st);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int dzg_solver_run(dzg_solver *s, int64_t max_new_iters)
+{
+    if (!s) return fail(DZG_E_ARG, "solver is NULL");
+    HIP_OK(hipSetDevice(s->opts.device));
+    TRY(read_ctl(s));
+    DzgCtl *h = s->h_ctl;
+    if (h->status != DZG_RUNNING && h->status != DZG_ITER_LIMIT) return h->status;
+    long long stop = s->opts.max_iter;
+    if (max_new_iters > 0 && h->iter + max_new_iters < stop) stop = h->iter + max_new_iters;
+    if (h->status == DZG_ITER_LIMIT && h->iter >= s->opts.max_iter) return h->status;
+    h->status = DZG_RUNNING;
+    h->iter_stop = stop;
+    // only these two words change; kernels are idle between runs
+    HIP_OK(hipMemcpyAsync(&s->d.ctl->status, &h->status, sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIP_OK(hipMemcpyAsync(&s->d.ctl->iter_stop, &h->iter_stop, sizeof(long long), hipMemcpyHostToDevice, s->st));
+    HIP_OK(hipStreamSynchronize(s->st));
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = s->numerics == DZG_NUMERICS_FAST ? run_fast(s) : run_strict(s);
+    auto t1 = std::chrono::steady_clock::now();
+    s->solve_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (rc != 0) return rc;
+    return s->h_ctl->status;
+}
+
+extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
+{
+    if (!s || !res) return fail(DZG_E_ARG, "NULL argument");
+    HIP_OK(hipSetDevice(s->opts.device));
+    TRY(read_ctl(s));
+    const DzgDev &d = s->d;
+    const int m = d.m, q = d.q;
+    res->status = s->h_ctl->status;
+    res->numerics_used = s->numerics;
+    res->iterations = s->h_ctl->iter;
+    std::vector<int> basis((size_t)(m ? m : 1)), nonbasis((size_t)(q ? q : 1));
+    std::vector<double> x((size_t)(m ? m : 1));
+    if (m) {
+        HIP_OK(hipMemcpy(basis.data(), d.basis, sizeof(int) * m, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(x.data(), d.x, sizeof(double) * m, hipMemcpyDeviceToHost));
+    }
+    if (q) HIP_OK(hipMemcpy(nonbasis.data(), d.nonbasis, sizeof(int) * q, hipMemcpyDeviceToHost));
+    // objective_value, src/simplex.rs:345-352, summed in basis-position order
+    double sum = 0.0;
+    for (int p = 0; p < m; ++p) {
+        const double prod = s->c_host[(size_t)basis[p]] * x[p];
+        sum = sum + prod;
+    }
+    res->objective = s->constant + sum;
+    if (res->basis) for (int p = 0; p < m; ++p) res->basis[p] = basis[p];
+    if (res->nonbasis) for (int k = 0; k < q; ++k) res->nonbasis[k] = nonbasis[k];
+    if (res->x && m) std::memcpy(res->x, x.data(), sizeof(double) * m);
+    if (res->xbar && m) HIP_OK(hipMemcpy(res->xbar, d.xbar, sizeof(double) * m, hipMemcpyDeviceToHost));
+    if (res->z && q) HIP_OK(hipMemcpy(res->z, d.z, sizeof(double) * q, hipMemcpyDeviceToHost));
+    if (res->zbar && q) HIP_OK(hipMemcpy(res->zbar, d.zbar, sizeof(double) * q, hipMemcpyDeviceToHost));
+    if (res->log && res->log_cap > 0) {
+        long long cnt = res->iterations < d.log_cap ? res->iterations : d.log_cap;
+        if (cnt > res->log_cap) cnt = res->log_cap;
+        if (cnt > 0) {
+            std::vector<int> kind((size_t)cnt), en((size_t)cnt), le((size_t)cnt);
+            std::vector<double> mu((size_t)cnt);
+            HIP_OK(hipMemcpy(kind.data(), d.log_kind, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(en.data(), d.log_enter, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(le.data(), d.log_leave, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(mu.data(), d.log_mu, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+            for (long long i = 0; i < cnt; ++i) {
+                res->log[i].kind = kind[(size_t)i];
+                res->log[i].reserved = 0;
+                res->log[i].entering = en[(size_t)i];
+                res->log[i].leaving = le[(size_t)i];
+                res->log[i].mu = mu[(size_t)i];
+            }
+        }
+    }
+    for (int c = 0; c < DZG_K_COUNT; ++c) {
+        res->kernel_ms[c] = s->kernel_ms[c];
+        res->kernel_launches[c] = s->kernel_launches[c];
+    }
+    res->price_bytes = s->h_ctl->price_bytes;
+    res->solve_ms = s->solve_ms;
+    return 0;
+}
+
+extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res)
+{
+    if (!res) return fail(DZG_E_ARG, "res is NULL");
+    dzg_solver *s = nullptr;
+    int rc = dzg_solver_create(lp, opts, &s);
+    if (rc != 0) return rc;
+    rc = dzg_solver_run(s, 0);
+    if (rc < 0) {
+        dzg_solver_destroy(s);
+        return rc;
+    }
+    int rc2 = dzg_solver_result(s, res);
+    dzg_solver_destroy(s);
+    return rc2 != 0 ? rc2 : rc;
+}
+
+// ---- single-function entry points for parity tests -------------------------------
+extern "C" int dzg_kernel_lu_solve(int64_t n, const double *a, const double *b, double *x_out,
+                                   double *lu_out, int64_t *p_out, int32_t device)
+{
+    if (n <= 0 || !a || !b || !x_out) return fail(DZG_E_ARG, "bad argument");
+    if (dzg_device_count() <= 0) return fail(DZG_E_DEVICE, "no HIP device visible");
+    HIP_OK(hipSetDevice(device));
+    const size_t nn = (size_t)n * (size_t)n;
+    double *lu, *lt, *urow, *krow, *lcol, *rhs;
+    int *piv;
+    DzgCtl *ctl;
+    HIP_OK(hipMalloc(&lu, sizeof(double) * nn));
+    HIP_OK(hipMalloc(&lt, sizeof(double) * nn));
+    HIP_OK(hipMalloc(&urow, sizeof(double) * n));
+    HIP_OK(hipMalloc(&krow, sizeof(double) * n));
+    HIP_OK(hipMalloc(&lcol, sizeof(double) * n));
+    HIP_OK(hipMalloc(&rhs, sizeof(double) * n));
+    HIP_OK(hipMalloc(&piv, sizeof(int) * n));
+    HIP_OK(hipMalloc(&ctl, sizeof(DzgCtl)));
+    DzgCtl c0;
+    std::memset(&c0, 0, sizeof(c0));
+    c0.status = DZG_RUNNING;
+    HIP_OK(hipMemcpy(ctl, &c0, sizeof(c0), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(lu, a, sizeof(double) * nn, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(rhs, b, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(piv, 0, sizeof(int) * n));
+    dzg_launch_lu_raw((int)n, lu, lt, piv, urow, krow, lcol, ctl, rhs, 0);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(x_out, rhs, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (lu_out) HIP_OK(hipMemcpy(lu_out, lu, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    if (p_out && n > 1) {
+        std::vector<int> p((size_t)n);
+        HIP_OK(hipMemcpy(p.data(), piv, sizeof(int) * n, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k + 1 < n; ++k) p_out[k] = p[(size_t)k];
+    }
+    hipFree(lu); hipFree(lt); hipFree(urow); hipFree(krow); hipFree(lcol); hipFree(rhs);
+    hipFree(piv); hipFree(ctl);
+    return 0;
+}
+
+extern "C" int dzg_kernel_neg_t_dot(int64_t m, int64_t n_struct, const double *a, int64_t lda,
+                                    const int64_t *cols, int64_t ncols, const double *v,
+                                    double *out, int32_t kernel, int32_t device)
+{
+    if (m <= 0 || n_struct < 0 || ncols < 0 || !v || !out || (ncols > 0 && !cols) ||
+        (n_struct > 0 && (!a || lda < m)))
+        return fail(DZG_E_ARG, "bad argument");
+    if (dzg_device_count() <= 0) return fail(DZG_E_DEVICE, "no HIP device visible");
+    HIP_OK(hipSetDevice(device));
+    const long long ldd = (m + 15) / 16 * 16;
+    const size_t abytes = sizeof(double) * (size_t)ldd * (size_t)(n_struct ? n_struct : 1);
+    double *dA, *dv, *dout;
+    int *dcols;
+    HIP_OK(hipMalloc(&dA, abytes));
+    HIP_OK(hipMalloc(&dv, sizeof(double) * ((size_t)m + 2)));
+    HIP_OK(hipMalloc(&dout, sizeof(double) * (size_t)(ncols ? ncols : 1)));
+    HIP_OK(hipMalloc(&dcols, sizeof(int) * (size_t)(ncols ? ncols : 1)));
+    HIP_OK(hipMemset(dA, 0, abytes));
+    HIP_OK(hipMemset(dv, 0, sizeof(double) * ((size_t)m + 2)));
+    if (n_struct > 0)
+        HIP_OK(hipMemcpy2D(dA, sizeof(double) * ldd, a, sizeof(double) * lda, sizeof(double) * m,
+                           n_struct, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dv, v, sizeof(double) * m, hipMemcpyHostToDevice));
+    std::vector<int> c32((size_t)(ncols ? ncols : 1));
+    for (int64_t k = 0; k < ncols; ++k) {
+        if (cols[k] >= n_struct || cols[k] < -m) return fail(DZG_E_ARG, "cols out of range");
+        c32[(size_t)k] = (int)cols[k];
+    }
+    HIP_OK(hipMemcpy(dcols, c32.data(), sizeof(int) * (size_t)(ncols ? ncols : 1), hipMemcpyHostToDevice));
+    dzg_launch_price_raw(kernel, (int)m, ldd, dA, dcols, (int)ncols, dv, dout, 0);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipGetLastError());
+    if (ncols > 0) HIP_OK(hipMemcpy(out, dout, sizeof(double) * ncols, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dv); hipFree(dout); hipFree(dcols);
+    return 0;
+}
+
+extern "C" int dzg_kernel_first_pivot(int64_t len, const double *y, const double *ybar,
+                                      int64_t *pos_out, int32_t device)
+{
+    if (len < 0 || !pos_out) return fail(DZG_E_ARG, "bad argument");
+    if (dzg_device_count() <= 0) return fail(DZG_E_DEVICE, "no HIP device visible");
+    HIP_OK(hipSetDevice(device));
+    return dzg_run_first_pivot(len, y, ybar, pos_out);
+}
+
+extern "C" int dzg_kernel_second_pivot(int64_t len, double mu, const double *y, const double *ybar,
+                                       const double *dy, int64_t *pos_out, int32_t device)
+{
+    if (len < 0 || !pos_out) return fail(DZG_E_ARG, "bad argument");
+    if (dzg_device_count() <= 0) return fail(DZG_E_DEVICE, "no HIP device visible");
+    HIP_OK(hipSetDevice(device));
+    return dzg_run_second_pivot(len, mu, y, ybar, dy, pos_out);
+}

@@ -1,0 +1,264 @@
+/*
+ * dantzig_amd.h -- C ABI of the MI355X-native parametric self-dual simplex core.
+ *
+ * This is the drop-in boundary for the hot path of matteosantama/dantzig
+ * (src/simplex.rs + src/linalg.rs).  The reference has no C ABI: its seam is the
+ * PyO3 function `dantzig.rust.solve` (src/lib.rs:16-27) and, inside Rust, the pair
+ * `Simplex::new(..)` / `Simplex::solve()` (src/simplex.rs:123, :332).  A Rust host
+ * binds this header with a plain `extern "C"` block (INTEGRATION.md shows the stub);
+ * the Python package binds it with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-allocated host memory
+ *     unless a parameter says "device"; the library never frees caller memory;
+ *   - no exceptions or unwinding cross this boundary: every entry point returns a
+ *     dzg_status (>= 0: solver outcome, < 0: call failed);
+ *   - one solve per handle at a time (thread-compatible, not thread-safe);
+ *   - all arithmetic is IEEE-754 binary64; indices are int64 at the boundary.
+ *
+ * Level 1 (dzg_solver_*, dzg_core_solve) takes the state `Simplex::new` leaves
+ * behind and replaces `Simplex::solve`.  Level 2 (dzg_model_solve) also replaces
+ * `Simplex::new` and `PySolution::from`, i.e. the whole of `dantzig.rust.solve`.
+ * The dzg_kernel_* entry points expose single reference functions for parity tests.
+ */
+#ifndef DANTZIG_AMD_H
+#define DANTZIG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DZG_ABI_VERSION 1
+
+/* Outcome codes.  0..2 mirror the reference: Ok / Error::Unbounded / Error::Infeasible
+ * (src/error.rs:3-7, src/simplex.rs:313,325).  The rest do not exist in the
+ * reference, which recurses without a cap and panics instead. */
+typedef enum {
+    DZG_OPTIMAL = 0,
+    DZG_UNBOUNDED = 1,
+    DZG_INFEASIBLE = 2,
+    DZG_ITER_LIMIT = 3,   /* stopped by max_iter / the run budget, state is resumable */
+    DZG_SINGULAR = 4,     /* fast numerics: basis inverse lost accuracy                */
+    DZG_PANIC = 5,        /* a reference panic path: safe_divide assert (src/simplex.rs:466),
+                             "unexpected code path" (:304), zero-row LP (n-1 underflow) */
+    DZG_RUNNING = 6,      /* internal: not terminated yet                              */
+    DZG_E_DEVICE = -1,    /* HIP error, or no usable GPU (the product has no CPU path) */
+    DZG_E_ARG = -2,       /* malformed input                                           */
+    DZG_E_NOMEM = -3
+} dzg_status;
+
+typedef enum { DZG_STEP_PRIMAL = 0, DZG_STEP_DUAL = 1 } dzg_step_kind;
+
+/* How dx = B^-1 a_j and v = B^-T e_p are obtained each iteration.
+ *  STRICT: exactly the reference's arithmetic -- gather B, dense LU with partial
+ *          pivoting of B and, separately, of B^T, forward/back substitution in the
+ *          reference's operation order (src/linalg.rs:88-128,282-299), unfused.
+ *          Bit-identical to the CPU restatement; O(m^3) per iteration.
+ *  FAST:   the basis inverse is kept resident in HBM and updated per pivot; FTRAN is
+ *          one GEMV, BTRAN one row read.  Same pivot rule; results agree with STRICT
+ *          up to rounding (pivot choices differ only on near-ties).
+ *  AUTO:   STRICT when m <= auto_strict_rows, else FAST. */
+typedef enum { DZG_NUMERICS_STRICT = 0, DZG_NUMERICS_FAST = 1, DZG_NUMERICS_AUTO = 2 } dzg_numerics;
+
+/* Pricing kernel choice for dz = -N^T v (src/linalg.rs:199-207). */
+typedef enum {
+    DZG_PRICE_AUTO = 0,
+    DZG_PRICE_SEQ = 1,   /* one lane per column through an LDS-transposed tile: sums in the
+                            reference's ascending-row order, bit-identical to neg_t_dot     */
+    DZG_PRICE_WAVE = 2   /* one wave per column, lane-strided partial sums + shuffle tree   */
+} dzg_price_kernel;
+
+/* The LP in the state `Simplex::new` produces (src/simplex.rs:209-223):
+ *      maximise  c.x + constant   subject to   [A_struct | slacks] x = rhs,  x >= 0
+ * Variables are numbered 0..n-1 in the reference's first-appearance order
+ * (src/simplex.rs:168-176).  Structural columns are stored dense column-major; slack
+ * columns are unit vectors and are never stored. */
+typedef struct {
+    int64_t m;               /* rows                                                    */
+    int64_t n;               /* all variables, structural + slack                       */
+    int64_t n_struct;        /* structural columns held in `a`                          */
+    const double *a;         /* column-major m x n_struct, leading dimension lda >= m   */
+    int64_t lda;
+    const int64_t *var_col;  /* n entries: >= 0 structural column of variable v;
+                                < 0: v is the slack of row (-1 - var_col[v]).
+                                NULL = benchmark convention: variable v <
+                                n_struct is column v, variable n_struct + i is slack i */
+    const double *c;         /* n objective coefficients (the core MAXIMISES)           */
+    double constant;
+    const int64_t *basis;    /* m   initial basic variable per position  (Simplex.b)    */
+    const int64_t *nonbasis; /* n-m initial nonbasic variable per position (Simplex.n)  */
+    const double *x;         /* m   initial x (= rhs)                                   */
+    const double *z;         /* n-m initial z (= -c of the nonbasic variables)          */
+} dzg_lp;
+
+typedef struct {
+    int32_t numerics;         /* dzg_numerics, default AUTO                             */
+    int32_t price_kernel;     /* dzg_price_kernel, default AUTO                         */
+    int32_t device;           /* HIP device ordinal, default 0                          */
+    int32_t auto_strict_rows; /* AUTO threshold, default 192                            */
+    int64_t max_iter;         /* default 10,000,000                                     */
+    double epsilon;           /* optimality tolerance, default 1e-12 (src/simplex.rs:9) */
+    int64_t log_capacity;     /* pivots kept in the device log, default min(max_iter, 2^22) */
+    int32_t poll_interval;    /* FAST: iterations enqueued between host status polls, default 32 */
+    int32_t profile;          /* 1: time every kernel class with HIP events (slower)    */
+    /* Column sharding (one process per GPU).  This rank prices the structural columns
+     * [col_begin, col_end); 0,0 = all.  See dzg_shard_* below. */
+    int64_t col_begin, col_end;
+    int32_t rank, world;
+} dzg_opts;
+
+typedef struct {
+    int32_t kind;       /* dzg_step_kind           */
+    int32_t reserved;
+    int64_t entering;   /* variable index j        */
+    int64_t leaving;    /* variable index i        */
+    double mu;
+} dzg_pivot;
+
+/* Kernel classes for the time/byte counters. */
+enum {
+    DZG_K_STATUS = 0, DZG_K_FTRAN, DZG_K_RATIO, DZG_K_BTRAN, DZG_K_PRICE, DZG_K_UPDATE,
+    DZG_K_BASIS_UPDATE, DZG_K_LU, DZG_K_COUNT
+};
+
+typedef struct {
+    int32_t status;          /* dzg_status                                              */
+    int32_t numerics_used;   /* STRICT or FAST                                          */
+    int64_t iterations;      /* executed pivots                                         */
+    double objective;        /* constant + sum c[basis[p]] * x[p]  (src/simplex.rs:345-352) */
+    /* optional outputs: NULL = not wanted */
+    int64_t *basis;          /* m                                                       */
+    int64_t *nonbasis;       /* n-m                                                     */
+    double *x, *xbar;        /* m                                                       */
+    double *z, *zbar;        /* n-m                                                     */
+    dzg_pivot *log;          /* log_cap entries, first min(iterations, log_cap) filled  */
+    int64_t log_cap;
+    /* counters, filled when opts.profile != 0 */
+    double kernel_ms[DZG_K_COUNT];
+    int64_t kernel_launches[DZG_K_COUNT];
+    double price_bytes;      /* algorithmic bytes of the pricing kernel, summed */
+    double solve_ms;         /* wall time inside dzg_solver_run, summed                  */
+} dzg_result;
+
+typedef struct dzg_solver dzg_solver;
+
+int dzg_abi_version(void);
+const char *dzg_status_str(int status);
+/* Last HIP / argument error message of the calling thread ("" if none). */
+const char *dzg_last_error(void);
+/* Number of visible HIP devices (0 if none): lets a host fail early and loudly. */
+int dzg_device_count(void);
+void dzg_opts_default(dzg_opts *opts);
+
+/* ---- Level 1: replaces Simplex::solve (src/simplex.rs:332-343) -------------------- */
+
+/* Validates the LP, uploads it to HBM and allocates the workspace.  Not timed by bench. */
+int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts, dzg_solver **out);
+/* Runs until Optimal / error or until `max_new_iters` more pivots were executed
+ * (<= 0: no budget).  Returns the status; DZG_ITER_LIMIT means "budget spent, call again". */
+int dzg_solver_run(dzg_solver *s, int64_t max_new_iters);
+/* Copies state, pivot log and counters back to the host. */
+int dzg_solver_result(dzg_solver *s, dzg_result *res);
+void dzg_solver_destroy(dzg_solver *s);
+/* create + run + result + destroy */
+int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res);
+
+/* ---- Level 2: replaces dantzig.rust.solve (src/lib.rs:16-27) ---------------------- */
+
+/* A model as the PyO3 layer hands it over: objective AffExpr (maximised) and a list of
+ * Inequality  coef.x <= b  over user variables with optional bounds
+ * (src/pyobjs.rs:10-152).  Terms keep expression order: it defines column order and
+ * therefore tie-breaks (src/simplex.rs:168-176). */
+typedef struct {
+    int64_t nvars;
+    const int32_t *has_lb, *has_ub;  /* nvars */
+    const double *lb, *ub;           /* nvars */
+    int64_t obj_nterms;
+    const int64_t *obj_var;          /* index into the variable table */
+    const double *obj_coef;
+    double obj_const;
+    int64_t ncons;
+    const int64_t *con_ptr;          /* ncons + 1 */
+    const int64_t *con_var;
+    const double *con_coef;
+    const double *con_b;             /* ncons */
+} dzg_model;
+
+typedef struct {
+    int32_t status;
+    int32_t numerics_used;
+    int64_t iterations;
+    double objective;     /* PySolution.objective_value (core sense: maximised)         */
+    double *values;       /* nvars: x+ - x- per user variable (src/simplex.rs:354-371)  */
+    int64_t m, n;         /* size of the standard form that was solved                  */
+} dzg_model_result;
+
+int dzg_model_solve(const dzg_model *model, const dzg_opts *opts, dzg_model_result *res);
+
+/* Host-only: the standard-form builder alone (Simplex::new, src/simplex.rs:123-224).
+ * Two-call protocol: first call with out->a == NULL fills m, n, n_struct and lda;
+ * the caller allocates a[lda*n_struct], var_col[n], c[n], basis[m], nonbasis[n-m],
+ * x[m], z[n-m], pos_var[nvars], neg_var[nvars] and calls again. */
+typedef struct {
+    int64_t m, n, n_struct, lda;
+    double *a;
+    int64_t *var_col;
+    double *c;
+    double constant;
+    int64_t *basis, *nonbasis;
+    double *x, *z;
+    int64_t *pos_var, *neg_var;  /* variable index of x+ / x- per user variable, -1 if unseen */
+} dzg_stdform;
+
+int dzg_build_standard_form(const dzg_model *model, dzg_stdform *out);
+
+/* ---- single reference functions on the GPU, for parity tests ---------------------- */
+
+/* lu_solve (src/linalg.rs:8-10): a is n*n ROW-major and is not modified; x_out[n].
+ * lu_out (n*n, may be NULL) and p_out (n-1, may be NULL) receive the packed factors
+ * exactly as Matrix::factorize leaves them (src/linalg.rs:88-128). */
+int dzg_kernel_lu_solve(int64_t n, const double *a, const double *b, double *x_out,
+                        double *lu_out, int64_t *p_out, int32_t device);
+
+/* collect_columns(cols).neg_t_dot(v) (src/linalg.rs:188-207) on a dense column-major
+ * matrix: out[k] = -sum_i a[i, cols[k]] * v[i]; cols[k] < 0 selects the unit column of
+ * row (-1 - cols[k]).  kernel: dzg_price_kernel. */
+int dzg_kernel_neg_t_dot(int64_t m, int64_t n_struct, const double *a, int64_t lda,
+                         const int64_t *cols, int64_t ncols, const double *v, double *out,
+                         int32_t kernel, int32_t device);
+
+/* find_first_pivot (src/simplex.rs:423-437): position or -1. */
+int dzg_kernel_first_pivot(int64_t len, const double *y, const double *ybar, int64_t *pos_out,
+                           int32_t device);
+/* find_second_pivot (src/simplex.rs:439-461): position or -1. */
+int dzg_kernel_second_pivot(int64_t len, double mu, const double *y, const double *ybar,
+                            const double *dy, int64_t *pos_out, int32_t device);
+
+/* ---- synthetic LPs of SURVEY 8(d) (host code, SplitMix64; used by bench and tests) -- */
+
+/* Generator G1: dense m x n_struct LP, primal- and dual-feasible by construction.
+ * a[lda*n_struct] column-major, b[m], c[n_struct]. */
+int dzg_gen_dense_lp(uint64_t seed, int64_t m, int64_t n_struct, double *a, int64_t lda,
+                     double *b, double *c);
+
+/* ---- column sharding over several GPUs, one process per GPU ------------------------
+ * The host (torch.distributed over RCCL, or any collective layer) moves the small
+ * exchange records between ranks; the library only produces and consumes them.
+ * See DESIGN.md "Multi-GPU". */
+typedef struct {
+    double ratio;       /* candidate ratio, -inf when this rank has none                 */
+    int64_t pos;        /* GLOBAL nonbasic position of the candidate, INT64_MAX if none   */
+    double y, ybar, dy; /* z, zbar, dz of the candidate (for the step lengths s, sbar)    */
+} dzg_candidate;
+
+/* Deterministic max-loc merge: largest ratio wins, lowest global position on ties --
+ * the sequential first-wins rule of src/simplex.rs:432-435,456-459.  Returns the index
+ * of the winning record, or -1 when every record is empty. */
+int64_t dzg_merge_candidates(const dzg_candidate *cands, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANTZIG_AMD_H */

@@ -1,0 +1,228 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact for indices (pivot log, basis) everywhere; bit-exact floats
+in STRICT numerics and for the order-preserving pricing kernel; 1e-9 relative on the
+objective in FAST numerics (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def core():
+    from dantzig_amd import core as c
+
+    return c
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_equal(got, want, what=""):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, what
+    # zeros of either sign compare equal (do not assert on zero signs)
+    same = (_bits(got) == _bits(want)) | ((got == 0.0) & (want == 0.0))
+    assert same.all(), f"{what}: {np.count_nonzero(~same)} of {same.size} values differ"
+
+
+# ------------------------------------------------------------------ lu_solve (src/linalg.rs)
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 64, 65, 130, 257])
+def test_lu_solve_bit_exact(core, n):
+    rng = np.random.default_rng(100 + n)
+    a = rng.uniform(-1, 1, (n, n))
+    b = rng.uniform(-1, 1, n)
+    x, lu, p = core.lu_solve(a, b)
+    want_lu, want_p = ora.lu_factorize(a)
+    assert p.tolist() == want_p.tolist()
+    assert_bit_equal(lu, want_lu, "packed LU")
+    assert_bit_equal(x, ora.lu_solve(a, b), "x")
+
+
+def test_lu_kats_on_gpu(core, kats):
+    k = kats["linalg"]["lu_factorization"]
+    _, lu, p = core.lu_solve(np.array(k["a"]), np.ones(3))
+    assert p.tolist() == k["p"] and lu.ravel().tolist() == k["lu"]
+    for s in kats["linalg"]["lu_solve"]:
+        x, _, _ = core.lu_solve(np.array(s["a"]), np.array(s["b"]))
+        assert x.tolist() == s["x"]
+
+
+def test_lu_integer_ties_and_zero_pivot(core):
+    # integer data: exact ties in the pivot search, exact zeros, a zero pivot column
+    rng = np.random.default_rng(5)
+    for n in (4, 9, 33):
+        a = rng.integers(-2, 3, (n, n)).astype(np.float64)
+        a[:, 1] = 0.0 if n == 4 else a[:, 1]
+        b = rng.integers(-3, 4, n).astype(np.float64)
+        x, lu, p = core.lu_solve(a, b)
+        want_lu, want_p = ora.lu_factorize(a)
+        assert p.tolist() == want_p.tolist()
+        assert_bit_equal(lu, want_lu)
+        want_x = ora.lu_solve(a, b)
+        ok = np.isfinite(want_x)
+        assert_bit_equal(x[ok], want_x[ok])
+        assert np.array_equal(np.isnan(x), np.isnan(want_x))
+
+
+# ------------------------------------------------------------------ neg_t_dot (src/linalg.rs)
+@pytest.mark.parametrize("m,ns", [(1, 1), (3, 4), (7, 5), (127, 33), (128, 32), (129, 31),
+                                  (300, 100), (1000, 257)])
+def test_neg_t_dot_seq_bit_exact(core, m, ns):
+    rng = np.random.default_rng(7 * m + ns)
+    a = rng.uniform(-1, 1, (m, ns))
+    a[rng.uniform(size=a.shape) < 0.2] = 0.0  # exact zeros are dropped by the reference's CSC
+    v = rng.uniform(-1, 1, m)
+    cols = np.concatenate([rng.permutation(ns), -1 - rng.integers(0, m, 5)])
+    rng.shuffle(cols)
+    full = np.concatenate([a, np.eye(m)], axis=1)
+    cp, ri, val = ora.csc_from_dense(full)
+    ocols = np.where(cols >= 0, cols, ns + (-1 - cols))
+    want = ora.neg_t_dot(cp, ri, val, ocols, v)
+    got = core.neg_t_dot(a, cols, v, kernel=core.PRICE_SEQ)
+    assert_bit_equal(got, want, "dz (sequential-order kernel)")
+    got_w = core.neg_t_dot(a, cols, v, kernel=core.PRICE_WAVE)
+    assert np.allclose(got_w, want, rtol=1e-12, atol=1e-13 * m)
+
+
+def test_neg_t_dot_kat(core, kats):
+    k = kats["linalg"]["neg_transpose_dot"]
+    for kern in (core.PRICE_SEQ, core.PRICE_WAVE):
+        got = core.neg_t_dot(np.array(k["a"]), [0, 1, 2, 3], np.array(k["v"]), kernel=kern)
+        assert got.tolist() == k["out"]
+
+
+# ------------------------------------------------------------------ pivot rules (src/simplex.rs)
+def test_first_and_second_pivot_match_oracle(core):
+    rng = np.random.default_rng(11)
+    for n in (1, 5, 64, 1000, 5000):
+        for trial in range(4):
+            y = rng.uniform(-1, 1, n)
+            ybar = rng.uniform(-0.5, 1, n)
+            dy = rng.uniform(-1, 1, n)
+            if trial >= 2:  # heavy ties, signed zeros, zero denominators -> +-inf, nan
+                y = rng.integers(-1, 2, n).astype(float)
+                ybar = rng.integers(0, 2, n).astype(float)
+                dy = rng.integers(-1, 2, n).astype(float)
+                y[rng.uniform(size=n) < 0.2] = -0.0
+            mu = float(rng.integers(0, 3)) if trial >= 2 else float(rng.uniform(0, 2))
+            assert core.first_pivot(y, ybar) == ora.find_first_pivot(y, ybar)
+            assert core.second_pivot(mu, y, ybar, dy) == ora.find_second_pivot(mu, y, ybar, dy)
+    assert core.first_pivot(np.array([1.0]), np.array([0.0])) == -1
+    assert core.second_pivot(1.0, np.array([-1.0]), np.ones(1), np.array([0.0])) == -1
+
+
+# ------------------------------------------------------------------ whole solves
+def _oracle_dense(core, seed, m, ns):
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    return core.CoreLP.from_inequality_form(a, b, c), want
+
+
+def _log(res):
+    return [(k, e, l) for k, e, l, _ in res.pivots]
+
+
+@pytest.mark.parametrize("seed,m,ns", [(1, 4, 8), (2, 16, 24), (3, 32, 64), (4, 64, 128),
+                                       (5, 96, 64), (6, 128, 256)])
+def test_strict_solve_is_bit_identical(core, seed, m, ns):
+    lp, want = _oracle_dense(core, seed, m, ns)
+    got = core.solve(lp, numerics=core.STRICT)
+    assert got.status == want.status == "optimal"
+    assert got.iterations == want.iterations
+    assert _log(got) == _log(want)
+    assert [p[3] for p in got.pivots] == [p[3] for p in want.pivots]  # mu, bit for bit
+    assert got.basis.tolist() == want.basis.tolist()
+    assert got.nonbasis.tolist() == want.nonbasis.tolist()
+    for name in ("x", "xbar", "z", "zbar"):
+        assert_bit_equal(getattr(got, name), getattr(want, name), name)
+    assert got.objective == want.objective
+
+
+@pytest.mark.parametrize("seed,m,ns", [(11, 32, 64), (12, 64, 128), (13, 128, 256),
+                                       (14, 200, 300), (15, 256, 512)])
+def test_fast_solve_matches_pivot_sequence(core, seed, m, ns):
+    lp, want = _oracle_dense(core, seed, m, ns)
+    for kern in (core.PRICE_SEQ, core.PRICE_WAVE):
+        got = core.solve(lp, numerics=core.FAST, price_kernel=kern)
+        assert got.status == want.status == "optimal"
+        assert _log(got) == _log(want), "pivot sequence differs from the reference's"
+        assert got.basis.tolist() == want.basis.tolist()
+        assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+        assert np.allclose(got.x, want.x, rtol=1e-9, atol=1e-9)
+
+
+def test_budgeted_runs_resume(core):
+    lp, want = _oracle_dense(core, 21, 64, 128)
+    with core.Solver(lp, numerics=core.FAST, poll_interval=4) as s:
+        steps = 0
+        while s.run(7) == "iter_limit":
+            steps += 1
+            assert steps < 10_000
+        got = s.result()
+    assert got.status == "optimal" and _log(got) == _log(want)
+
+
+def test_iteration_cap(core):
+    lp, want = _oracle_dense(core, 22, 32, 64)
+    got = core.solve(lp, numerics=core.STRICT, max_iter=5)
+    assert got.status == "iter_limit" and got.iterations == 5
+    assert _log(got) == _log(want)[:5]
+
+
+# ------------------------------------------------------------------ reference solver KATs
+def _names(kind):
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_kats.json")) as f:
+        return [k["name"] for k in json.load(f)[kind]]
+
+
+@pytest.mark.parametrize("name", _names("solver"))
+def test_reference_solver_kats_through_level2(kats, name):
+    """src/simplex.rs:484-796 through dzg_model_solve (builder + GPU core + solution)."""
+    import ctypes as C
+
+    from dantzig_amd import _ffi
+
+    k = next(s for s in kats["solver"] if s["name"] == name)
+    md = k["model"]
+    V = len(md["vars"])
+    f64, i64 = _ffi.f64, _ffi.i64
+    has_lb = np.array([v["lb"] is not None for v in md["vars"]] + [0], dtype=np.int32)
+    has_ub = np.array([v["ub"] is not None for v in md["vars"]] + [0], dtype=np.int32)
+    lb = f64([v["lb"] or 0.0 for v in md["vars"]] + [0.0])
+    ub = f64([v["ub"] or 0.0 for v in md["vars"]] + [0.0])
+    ot = md["objective"]["terms"]
+    ov, oc = i64([t[0] for t in ot] + [0]), f64([t[1] for t in ot] + [0.0])
+    ptr_, cv, cc, cb = [0], [], [], []
+    for con in md["constraints"]:
+        cv += [t[0] for t in con["terms"]]
+        cc += [t[1] for t in con["terms"]]
+        ptr_.append(len(cv))
+        cb.append(con["b"])
+    cp, cva, cca, cba = i64(ptr_), i64(cv + [0]), f64(cc + [0.0]), f64(cb + [0.0])
+    p = _ffi.ptr
+    model = _ffi.Model(V, p(has_lb), p(has_ub), p(lb), p(ub), len(ot), p(ov), p(oc),
+                       md["objective"]["constant"], len(cb), p(cp), p(cva), p(cca), p(cba))
+    want = ora.solve_model(md)
+    for numerics in (_ffi.STRICT, _ffi.FAST):
+        values = np.zeros(V + 1)
+        res = _ffi.ModelResult()
+        res.values = p(values)
+        opts = _ffi.default_opts(numerics=numerics)
+        rc = _ffi.check(_ffi.lib().dzg_model_solve(C.byref(model), C.byref(opts), C.byref(res)),
+                        "dzg_model_solve")
+        assert _ffi.status_str(rc) == k["expect"]["status"] == want.status
+        if want.status == "optimal":
+            assert abs(res.objective - k["expect"]["objective"]) <= 1e-12
+            assert np.allclose(values[:V], k["expect"]["values"], rtol=0, atol=1e-12)
+            if numerics == _ffi.STRICT:
+                assert res.objective == want.objective
+                assert values[:V].tolist() == want.values.tolist()
+                assert res.iterations == want.iterations
