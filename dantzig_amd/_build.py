@@ -34,7 +34,7 @@ def _newest(paths) -> float:
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, "common.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "k_price_kernels.h"),
             os.path.join(os.path.dirname(HERE), "include", "dantzig_amd.h")]
     return hdrs
 

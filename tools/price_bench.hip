@@ -1,0 +1,99 @@
+// price_bench.hip -- microbenchmark of pricing-kernel variants (diagnostic tool, not shipped).
+// usage: price_bench [m] [ns] [reps]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../dantzig_amd/csrc/k_price_kernels.h"
+
+#define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+__global__ void k_fill(double *a, size_t n, unsigned long long seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        a[i] = 2.0 * ((double)(z >> 11) * 0x1.0p-53) - 1.0;
+    }
+}
+
+// pure read stream: the practical HBM read roofline for this access shape
+template <int U>
+__global__ __launch_bounds__(256) void k_stream(const double *__restrict__ a, size_t n2, double *out)
+{
+    const double2_t *p = reinterpret_cast<const double2_t *>(a);
+    double acc = 0.0;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n2; i += U * stride) {
+        double2_t c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += c[u].x + c[u].y;
+    }
+    if (acc == 1.2345) out[0] = acc;
+}
+
+int main(int argc, char **argv)
+{
+    int m = argc > 1 ? atoi(argv[1]) : 8192;
+    int ns = argc > 2 ? atoi(argv[2]) : 16384;
+    int reps = argc > 3 ? atoi(argv[3]) : 20;
+    long long lda = (m + 15) / 16 * 16;
+    size_t na = (size_t)lda * ns;
+    double *A, *v, *dz, *ref;
+    int *cols;
+    CK(hipMalloc(&A, na * 8)); CK(hipMalloc(&v, (m + 16) * 8)); CK(hipMalloc(&dz, ns * 8)); CK(hipMalloc(&ref, ns * 8));
+    CK(hipMalloc(&cols, ns * 4));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, na, 1ull);
+    CK(hipMemset(v, 0, (m + 16) * 8));
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, v, (size_t)m, 2ull);
+    std::vector<int> h(ns);
+    for (int i = 0; i < ns; ++i) h[i] = i;
+    CK(hipMemcpy(cols, h.data(), ns * 4, hipMemcpyHostToDevice));
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double gbytes = 8.0 * m * (double)ns / 1e9;
+
+    auto time_it = [&](const char *name, auto launch, bool check) {
+        launch(); // warm
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        double us = 1e3 * ms / reps;
+        double maxdiff = -1;
+        if (check) {
+            std::vector<double> a(ns), b(ns);
+            CK(hipMemcpy(a.data(), dz, ns * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), ref, ns * 8, hipMemcpyDeviceToHost));
+            maxdiff = 0;
+            for (int i = 0; i < ns; ++i) { double d = a[i] - b[i]; if (d < 0) d = -d; if (d > maxdiff) maxdiff = d; }
+        }
+        printf("%-28s %9.1f us  %7.1f GB/s  (%.1f%% of 8 TB/s)  maxdiff %.2e\n", name, us, gbytes / (us * 1e-6), 100.0 * gbytes / (us * 1e-6) / 8000.0, maxdiff);
+        fflush(stdout);
+    };
+
+    // reference result
+    hipLaunchKernelGGL((k_price_seq<32, 128>), dim3((ns + 31) / 32), dim3(256), 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, ref);
+    CK(hipDeviceSynchronize());
+
+    time_it("stream U=4 (2048 blk)", [&] { hipLaunchKernelGGL((k_stream<4>), dim3(2048), dim3(256), 0, 0, A, na / 2, dz); }, false);
+    time_it("stream U=8 (2048 blk)", [&] { hipLaunchKernelGGL((k_stream<8>), dim3(2048), dim3(256), 0, 0, A, na / 2, dz); }, false);
+    time_it("stream U=8 (4096 blk)", [&] { hipLaunchKernelGGL((k_stream<8>), dim3(4096), dim3(256), 0, 0, A, na / 2, dz); }, false);
+#define SEQ(C, TR) time_it("seq<" #C "," #TR ">", [&] { hipLaunchKernelGGL((k_price_seq<C, TR>), dim3((ns + C - 1) / C), dim3(256), 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, dz); }, true)
+    SEQ(32, 128); SEQ(32, 256); SEQ(16, 256); SEQ(64, 128); SEQ(16, 512); SEQ(16, 128); SEQ(8, 512);
+    time_it("wave (v0, 2048x256)", [&] { hipLaunchKernelGGL(k_price_wave, dim3(2048), dim3(256), 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, dz); }, true);
+#define WAVE2(U, VL, BLK, THR) time_it("wave2<" #U "," #VL "> " #BLK "x" #THR, [&] { hipLaunchKernelGGL((k_price_wave2<U, VL>), dim3(BLK), dim3(THR), VL ? (size_t)(m + 2) * 8 : 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, dz); }, true)
+    WAVE2(4, false, 2048, 256); WAVE2(8, false, 2048, 256); WAVE2(8, false, 1024, 512);
+    WAVE2(4, true, 512, 1024); WAVE2(8, true, 512, 1024); WAVE2(8, true, 256, 1024); WAVE2(4, true, 512, 512);
+    WAVE2(2, true, 512, 1024); WAVE2(16, false, 2048, 256);
+    return 0;
+}
