@@ -30,10 +30,17 @@ struct DzgCtl {
     // strict LU step scratch
     int lu_mu;
     int lu_pivot_zero;
-    // fast numerics health
-    double max_growth;
+    // fast numerics: compact basis inverse + pending eta file
+    int ncompact;        // dense columns of Binv0 in compact storage ("k")
+    int neta;            // pending rank-1 updates not yet folded into Binv0
     int pad0, pad1;
 };
+
+// Partial-reduction fan-in sizes of the FAST pipeline (fixed grids => fixed counts)
+#define DZG_NB_UPD 64     // blocks of k_fast_update      -> first-pivot partials per side
+#define DZG_NB_GEMV 512   // blocks of k_fast_gemv        -> primal ratio partials
+#define DZG_NW_PRICE 1024 // waves of the pricing kernels -> dual ratio partials
+#define DZG_RMAX 64       // eta-file capacity = rank of one MFMA flush
 
 // argmax candidate: k < 0 means "none"
 struct DzgCand {
@@ -123,8 +130,21 @@ struct DzgDev {
     int *log_kind, *log_enter, *log_leave;
     double *log_mu;
     long long log_cap;
-    // fast numerics
-    double *binv; // m x m row-major
+    // fast numerics (k_fast.hip): Binv = Binv0 - U W^T
+    double *binv;      // Binv0, compact row-major: m rows x ncompact dense columns, stride ldb
+    long long ldb;
+    int *drow;         // [m] constraint row of compact column c
+    int *dslot;        // [m] compact column of constraint row r, or -1 (unit column)
+    double *U;         // [m][DZG_RMAX] eta columns, row-major
+    double *W;         // [DZG_RMAX][ldw] eta rows (each W_t contiguous)
+    long long ldw;
+    double *Wc;        // [DZG_RMAX][ldw] W gathered to compact coordinates (flush scratch)
+    double *ag;        // [m] entering column gathered to compact coordinates
+    double *beta;      // [DZG_RMAX] W_t . a_j
+    int *plist;        // [q] nonbasic positions holding structural variables (first nb_struct)
+    int *pslot;        // [q] index into plist or -1
+    double *fpx_r, *fpz_r, *rx_r, *rz_r; // partial candidates (ratios)
+    int *fpx_k, *fpz_k, *rx_k, *rz_k;    // partial candidates (positions)
     // strict numerics
     double *lu;   // m x m row-major workspace
     double *lt;   // m x m: multipliers, column k contiguous
@@ -146,6 +166,8 @@ int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *
 
 // k_price.hip
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
+void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st);
+int dzg_price_partials(int kernel);
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st);
 
@@ -159,6 +181,9 @@ void dzg_launch_lu_raw(int n, double *lu, double *lt, int *piv, double *urow, do
 
 // k_fast.hip
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st);
-void dzg_launch_fast_ftran(const DzgDev &d, int need_kind, hipStream_t st);
+void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, hipStream_t st);
+void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, hipStream_t st);
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st);
-void dzg_launch_fast_update(const DzgDev &d, hipStream_t st);
+void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st);
+void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st);
+void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st);

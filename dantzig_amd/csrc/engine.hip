@@ -82,8 +82,7 @@ struct dzg_solver {
     std::vector<double> c_host;
     double constant = 0.0;
     double solve_ms = 0.0;
-    long long iter_known = 0;
-    int status_known = DZG_RUNNING;
+    int since_flush = 0; // iterations enqueued since the eta file was last folded into Binv0
     // profiling
     std::vector<hipEvent_t> ev; // [batch slot][class][2]
     double kernel_ms[DZG_K_COUNT] = {};
@@ -273,8 +272,24 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                                        "builds it); use STRICT for an arbitrary starting basis");
             row_seen[(size_t)(-1 - code)] = 1;
         }
-        TRY(dev_alloc(s, &d.binv, (size_t)m * (size_t)m));
+        // row stride: not a multiple of a large power of two, so that the first k columns of
+        // consecutive rows do not all land on the same HBM channels
+        d.ldb = ((long long)m + 15) / 16 * 16 + 32;
+        d.ldw = ((long long)m + 15) / 16 * 16 + 64;
+        TRY(dev_alloc(s, &d.binv, (size_t)(m ? m : 1) * (size_t)d.ldb));
+        TRY(dev_alloc(s, &d.drow, (size_t)m)); TRY(dev_alloc(s, &d.dslot, (size_t)m));
+        TRY(dev_alloc(s, &d.U, (size_t)(m ? m : 1) * DZG_RMAX));
+        TRY(dev_alloc(s, &d.W, (size_t)d.ldw * DZG_RMAX));
+        TRY(dev_alloc(s, &d.Wc, (size_t)d.ldw * DZG_RMAX));
+        TRY(dev_alloc(s, &d.ag, (size_t)m + 2)); TRY(dev_alloc(s, &d.beta, (size_t)DZG_RMAX));
+        TRY(dev_alloc(s, &d.plist, (size_t)q)); TRY(dev_alloc(s, &d.pslot, (size_t)q));
+        const size_t np = 4096;
+        TRY(dev_alloc(s, &d.fpx_r, np)); TRY(dev_alloc(s, &d.fpz_r, np));
+        TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));
+        TRY(dev_alloc(s, &d.fpx_k, np)); TRY(dev_alloc(s, &d.fpz_k, np));
+        TRY(dev_alloc(s, &d.rx_k, np)); TRY(dev_alloc(s, &d.rz_k, np));
         dzg_launch_fast_init(d, s->st);
+        dzg_launch_fast_update(d, 1, s->st); // first-pivot partials of the initial state
     } else {
         TRY(dev_alloc(s, &d.lu, (size_t)m * (size_t)m));
         TRY(dev_alloc(s, &d.lt, (size_t)m * (size_t)m));
@@ -321,30 +336,36 @@ static void enqueue_fast_iteration(dzg_solver *s, int slot)
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     Prof pf{s, slot};
+    const int pk = price_kernel_for(s);
     pf.begin(DZG_K_STATUS);
-    dzg_launch_status(d, st);
+    dzg_launch_fast_select_prep(d, 0, 0, st); // status() + FTRAN prep of a primal step
     pf.end(DZG_K_STATUS);
     pf.begin(DZG_K_FTRAN);
-    dzg_launch_fast_ftran(d, DZG_STEP_PRIMAL, st); // primal step: dx first
+    dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, st); // primal step: dx first (+ ratio partials)
     pf.end(DZG_K_FTRAN);
-    pf.begin(DZG_K_RATIO);
-    dzg_launch_ratio(d, DZG_STEP_PRIMAL, st);
-    pf.end(DZG_K_RATIO);
     pf.begin(DZG_K_BTRAN);
-    dzg_launch_fast_btran(d, st);
+    dzg_launch_fast_btran(d, st); // (primal: finishes the ratio test) v = row p of Binv
     pf.end(DZG_K_BTRAN);
     pf.begin(DZG_K_PRICE);
-    dzg_launch_price(d, price_kernel_for(s), st);
+    dzg_launch_price_fast(d, pk, st); // dz (+ dual ratio partials)
     pf.end(DZG_K_PRICE);
-    dzg_launch_ratio(d, DZG_STEP_DUAL, st);
-    dzg_launch_fast_ftran(d, DZG_STEP_DUAL, st); // dual step: dx last
+    pf.begin(DZG_K_RATIO);
+    dzg_launch_fast_select_prep(d, 1, dzg_price_partials(pk), st); // dual: ratio test + prep
+    dzg_launch_fast_gemv(d, DZG_STEP_DUAL, st);                    // dual step: dx last
+    pf.end(DZG_K_RATIO);
     pf.begin(DZG_K_UPDATE);
-    dzg_launch_prepare(d, st);
-    dzg_launch_update_vectors(d, st);
+    dzg_launch_fast_pivot(d, st);
+    dzg_launch_fast_update(d, 0, st);
     pf.end(DZG_K_UPDATE);
-    pf.begin(DZG_K_BASIS_UPDATE);
-    dzg_launch_fast_update(d, st);
-    pf.end(DZG_K_BASIS_UPDATE);
+    if (++s->since_flush >= DZG_RMAX) {
+        pf.begin(DZG_K_BASIS_UPDATE);
+        dzg_launch_fast_flush(d, st); // Binv0 -= U Wc on the fp64 matrix cores
+        pf.end(DZG_K_BASIS_UPDATE);
+        s->since_flush = 0;
+    } else {
+        pf.begin(DZG_K_BASIS_UPDATE);
+        pf.end(DZG_K_BASIS_UPDATE);
+    }
 }
 
 static void collect_profile(dzg_solver *s, int slots_real)

@@ -1,166 +1,654 @@
 // k_fast.hip -- FAST numerics: the basis inverse stays resident in HBM.
 //
 // The reference refactorises B and B^T from scratch in every iteration
-// (src/simplex.rs:228,234 -> src/linalg.rs:88-128), (4/3)m^3 flops per pivot.  On an
-// MI355X the same two vectors are obtained from a resident row-major inverse Binv:
+// (src/simplex.rs:228,234 -> src/linalg.rs:88-128), (4/3)m^3 flops per pivot, and then runs
+// two triangular solves (src/linalg.rs:282-299).  Triangular solves are chains of dependent
+// steps -- latency-bound on a GPU -- so this engine keeps an explicit inverse instead and turns
+// both solves into bandwidth-bound streaming:
 //
-//   dx = B^-1 a_j          one GEMV over Binv, one wave per row, coalesced 16-B loads
-//   v  = B^-T e_p          row p of Binv: a contiguous 8*m-byte read, no solve at all
-//   pivot                  Binv <- E * Binv (rank-1): row_p /= dx_p, row_i -= dx_i * row_p
+//      Binv = Binv0 - U W^T                                   (product form, <= 64 pending etas)
 //
-// Triangular solves are latency-bound chains of m/nb dependent steps on a GPU; the explicit
-// inverse turns both solves into bandwidth-bound streaming, which is what 8 TB/s of HBM
-// and 288 GB of capacity are for.  It also row-shards over GPUs (DESIGN.md "Multi-GPU").
-// The initial basis is the slack identity (src/simplex.rs:190-201), so Binv starts as a
-// permutation matrix and no factorisation is needed to start.
+//   * Binv0 is stored COMPACT: only the columns that belong to rows whose slack is nonbasic
+//     are dense; the column of a row whose slack is basic at position p is the unit vector
+//     e_p and is never stored (B = [A_S | E] => B^-1 has the same structure).  The basis
+//     starts as the slack identity (src/simplex.rs:190-201), so Binv0 starts EMPTY: no
+//     factorisation is needed to start, and FTRAN costs 8*m*k bytes with k = #structural
+//     basics instead of 8*m^2.
+//   * FTRAN  dx = B^-1 a_j :  one GEMV over the compact Binv0 (one wave per row, coalesced
+//     16-B loads), the unit columns contribute a_j[r] at the slack's position, the eta file
+//     contributes -U (W^T a_j).
+//   * BTRAN  v = B^-T e_p  :  row p of Binv -- a gather from one compact row minus a skinny
+//     GEMV over W.  No solve at all.
+//   * pivot: append u = (dx - e_p)/dx_p and w = v to the eta file (O(m)); a leaving slack
+//     appends a compact column, an entering slack deletes one (swap with the last).
+//   * every 64 pivots the eta file is folded into Binv0 by one rank-64 update
+//     Binv0 -= U * Wc on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): the only true GEMM
+//     on the path.
+//
+// The selection logic (src/simplex.rs:274-306 status, :423-461 pivot rules) is fused into
+// the heads of these kernels: each workgroup reduces the small arrays of per-workgroup
+// partial candidates left by the previous kernel (deterministic max-loc, lowest position on
+// ties), workgroup 0 publishes the decision in the control block for the next kernel.
 #include "common.h"
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_fast_init(double *__restrict__ binv, int m,
-                                                   const int *__restrict__ basis,
-                                                   const int *__restrict__ var_col)
+#define R_ DZG_RMAX
+
+__device__ __forceinline__ DzgCand reduce_partials(const double *__restrict__ pr,
+                                                   const int *__restrict__ pk, int count)
 {
-    // B = [e_{r_0} e_{r_1} ...] (position p holds the slack of row r_p)  =>  Binv[p][r_p] = 1
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < m) {
-        const int code = var_col[basis[p]];
-        binv[(long long)p * m + (-1 - code)] = 1.0;
+    DzgCand best;
+    best.r = 0.0;
+    best.k = -1;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        DzgCand c;
+        c.r = pr[i];
+        c.k = pk[i];
+        best = dzg_better(best, c);
+    }
+    return dzg_block_best(best);
+}
+
+__device__ __forceinline__ double block_sum(double x)
+{
+    __shared__ double s_sum[16];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, DZG_WAVE);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_sum[w];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------
+// k_fast_select_prep<MODE>
+//   MODE 0: head of the iteration.  status(): first pivots on both sides from the partials
+//           left by k_fast_update, optimality test, primal/dual choice (src/simplex.rs:274-306).
+//           If primal: FTRAN preparation for the entering column.
+//   MODE 1: dual step after pricing: ratio test on the z side from the pricing kernel's
+//           partials (src/simplex.rs:324-325), then FTRAN preparation.
+//   FTRAN preparation: workgroup t < neta computes beta_t = W_t . a_j; the last workgroup
+//   gathers a_j into compact coordinates (ag[c] = a_j[drow[c]]).
+// grid = DZG_RMAX + 1 workgroups of 256.
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fast_select_prep(
+    DzgCtl *ctl, int m, const double *__restrict__ A, long long lda,
+    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const double *__restrict__ fpx_r, const int *__restrict__ fpx_k,
+    const double *__restrict__ fpz_r, const int *__restrict__ fpz_k,
+    const double *__restrict__ rz_r, const int *__restrict__ rz_k, int nrz,
+    const double *__restrict__ W, long long ldw, const int *__restrict__ drow,
+    double *__restrict__ ag, double *__restrict__ beta, double eps)
+{
+    if (ctl->status != DZG_RUNNING) return;
+    int epos;
+    if (MODE == 0) {
+        const DzgCand cj = reduce_partials(fpz_r, fpz_k, DZG_NB_UPD);
+        const DzgCand ci = reduce_partials(fpx_r, fpx_k, DZG_NB_UPD);
+        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+        int kind;
+        double mu;
+        if (cj.k >= 0 && ci.k >= 0) {
+            const double primal = ci.r, dual = cj.r;
+            if (primal <= eps && dual <= eps) {
+                if (lead) ctl->status = DZG_OPTIMAL;
+                return;
+            }
+            if (primal < dual) {
+                kind = DZG_STEP_PRIMAL;
+                mu = dual;
+            } else {
+                kind = DZG_STEP_DUAL;
+                mu = primal;
+            }
+        } else if (cj.k >= 0) {
+            kind = DZG_STEP_PRIMAL;
+            mu = cj.r;
+        } else if (ci.k >= 0) {
+            kind = DZG_STEP_DUAL;
+            mu = ci.r;
+        } else {
+            if (lead) ctl->status = DZG_PANIC;
+            return;
+        }
+        if (ctl->iter >= ctl->iter_stop) {
+            if (lead) ctl->status = DZG_ITER_LIMIT;
+            return;
+        }
+        if (m == 0) {
+            if (lead) ctl->status = DZG_PANIC;
+            return;
+        }
+        if (lead) {
+            ctl->kind = kind;
+            ctl->mu = mu;
+            ctl->enter_pos = kind == DZG_STEP_PRIMAL ? cj.k : -1;
+            ctl->leave_pos = kind == DZG_STEP_DUAL ? ci.k : -1;
+        }
+        if (kind != DZG_STEP_PRIMAL) return;
+        epos = cj.k;
+    } else {
+        if (ctl->kind != DZG_STEP_DUAL) return;
+        const DzgCand c = reduce_partials(rz_r, rz_k, nrz);
+        if (c.k < 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status = DZG_INFEASIBLE; // :325
+            return;
+        }
+        epos = c.k;
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_pos = epos;
+    }
+    // ---- FTRAN preparation for the entering variable
+    const int code = var_col[nonbasis[epos]];
+    const int neta = ctl->neta, k = ctl->ncompact;
+    const int b = blockIdx.x;
+    if (b < R_) {
+        if (b >= neta) return;
+        const double *wt = W + (long long)b * ldw;
+        if (code < 0) {
+            if (threadIdx.x == 0) beta[b] = wt[-1 - code];
+            return;
+        }
+        const double *a = A + (long long)code * lda;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) acc = fma(wt[i], a[i], acc);
+        acc = block_sum(acc);
+        if (threadIdx.x == 0) beta[b] = acc;
+    } else {
+        if (code < 0) {
+            const int rr = -1 - code;
+            for (int c = threadIdx.x; c < k; c += blockDim.x) ag[c] = (drow[c] == rr) ? 1.0 : 0.0;
+        } else {
+            const double *a = A + (long long)code * lda;
+            for (int c = threadIdx.x; c < k; c += blockDim.x) ag[c] = a[drow[c]];
+        }
+        // pad to a multiple of 2 so the GEMV can read 16 B at a time
+        if (threadIdx.x == 0 && (k & 1)) ag[k] = 0.0;
     }
 }
 
-// dx = Binv * a_j.  One wave per row, rows strided over the grid.
-__global__ __launch_bounds__(256) void k_fast_ftran(const DzgCtl *ctl, int need_kind,
-                                                    const double *__restrict__ binv, int m,
-                                                    const double *__restrict__ A, long long lda,
-                                                    const int *__restrict__ nonbasis,
-                                                    const int *__restrict__ var_col,
-                                                    double *__restrict__ dx)
+// ---------------------------------------------------------------------------------
+// k_fast_gemv: dx = Binv a_j.  LPR lanes cooperate on one row (64 when the compact width k is
+// large, 16 when it is small so that a wave covers 4 rows per pass).  A primal step also leaves
+// the per-workgroup ratio-test candidates (src/simplex.rs:439-461) for k_fast_btran.
+// grid = DZG_NB_GEMV workgroups of 256.
+// ---------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int m, int k, int neta,
+                                          int code, const double *__restrict__ binv,
+                                          long long ldb, const double *__restrict__ ag,
+                                          const double *__restrict__ U,
+                                          const double *__restrict__ beta,
+                                          const double *__restrict__ A, long long lda,
+                                          const int *__restrict__ basis,
+                                          const int *__restrict__ var_col,
+                                          const double *__restrict__ x,
+                                          const double *__restrict__ xbar,
+                                          double *__restrict__ dx, DzgCand &best)
+{
+    constexpr int RPW = 64 / LPR; // rows per wave and pass
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int k2 = (k + 1) & ~1;
+    const double mu = ctl->mu;
+    for (int i0 = wave_global * RPW; i0 < m; i0 += nwaves * RPW) {
+        const int i = i0 + grp;
+        double acc = 0.0;
+        if (i < m) {
+            const double *row = binv + (long long)i * ldb;
+            double a0 = 0.0, a1 = 0.0;
+            int c = 2 * sub;
+            for (; c + 2 * LPR < k2; c += 4 * LPR) {
+                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
+                const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 2 * LPR);
+                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+                const double2_t g1 = *reinterpret_cast<const double2_t *>(ag + c + 2 * LPR);
+                a0 = fma(r0.x, g0.x, a0);
+                a1 = fma(r1.x, g1.x, a1);
+                a0 = fma(r0.y, g0.y, a0);
+                a1 = fma(r1.y, g1.y, a1);
+            }
+            for (; c < k2; c += 2 * LPR) {
+                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
+                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+                a0 = fma(r0.x, g0.x, a0);
+                a0 = fma(r0.y, g0.y, a0);
+            }
+            acc = a0 + a1;
+            const double *ui = U + (long long)i * R_;
+            for (int t = sub; t < neta; t += LPR) acc = fma(-ui[t], beta[t], acc);
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+        if (i < m && sub == 0) {
+            const int bc = var_col[basis[i]];
+            if (bc < 0) { // position i holds the slack of row rr: unit column contributes a_j[rr]
+                const int rr = -1 - bc;
+                acc += code >= 0 ? A[(long long)code * lda + rr] : ((-1 - code) == rr ? 1.0 : 0.0);
+            }
+            dx[i] = acc;
+            if (need_kind == DZG_STEP_PRIMAL) {
+                const double scaled = mu * xbar[i];
+                const double den = x[i] + scaled;
+                DzgCand cnd;
+                cnd.r = acc / den;
+                cnd.k = i;
+                if (cnd.r > 0.0) best = dzg_better(best, cnd);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fast_gemv(
+    const DzgCtl *ctl, int need_kind, int m, const double *__restrict__ binv, long long ldb,
+    const double *__restrict__ ag, const double *__restrict__ U, const double *__restrict__ beta,
+    const double *__restrict__ A, long long lda, const int *__restrict__ basis,
+    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
+    double *__restrict__ rx_r, int *__restrict__ rx_k)
 {
     if (ctl->status != DZG_RUNNING || ctl->kind != need_kind) return;
+    const int k = ctl->ncompact, neta = ctl->neta;
     const int code = var_col[nonbasis[ctl->enter_pos]];
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    if (code < 0) { // entering slack: a_j = e_r, dx = column r of Binv
-        const int r = -1 - code;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
-            dx[i] = binv[(long long)i * m + r];
-        return;
-    }
-    const double *a = A + (long long)code * lda;
-    const int m2 = m & ~1;
-    for (int i = wave_global; i < m; i += nwaves) {
-        const double *row = binv + (long long)i * m;
-        double a0 = 0.0, a1 = 0.0;
-        if ((m & 1) == 0) {
-            int c = 2 * lane;
-            for (; c + 128 < m2; c += 256) {
-                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-                const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 128);
-                const double2_t x0 = *reinterpret_cast<const double2_t *>(a + c);
-                const double2_t x1 = *reinterpret_cast<const double2_t *>(a + c + 128);
-                a0 = fma(r0.x, x0.x, a0);
-                a1 = fma(r1.x, x1.x, a1);
-                a0 = fma(r0.y, x0.y, a0);
-                a1 = fma(r1.y, x1.y, a1);
-            }
-            for (; c < m2; c += 128) {
-                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-                const double2_t x0 = *reinterpret_cast<const double2_t *>(a + c);
-                a0 = fma(r0.x, x0.x, a0);
-                a0 = fma(r0.y, x0.y, a0);
-            }
-        } else { // odd m: rows are only 8-B aligned
-            for (int c = lane; c < m; c += 64) a0 = fma(row[c], a[c], a0);
+    DzgCand best;
+    best.r = 0.0;
+    best.k = -1;
+    if (k > 512)
+        gemv_rows<64>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, beta, A, lda, basis,
+                      var_col, x, xbar, dx, best);
+    else
+        gemv_rows<16>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, beta, A, lda, basis,
+                      var_col, x, xbar, dx, best);
+    if (need_kind == DZG_STEP_PRIMAL) {
+        best = dzg_block_best(best);
+        if (threadIdx.x == 0) {
+            rx_r[blockIdx.x] = best.r;
+            rx_k[blockIdx.x] = best.k;
         }
-        double acc = a0 + a1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
-        if (lane == 0) dx[i] = acc;
     }
 }
 
-// v = row leave_pos of Binv
-__global__ __launch_bounds__(256) void k_fast_btran(const DzgCtl *ctl,
-                                                    const double *__restrict__ binv, int m,
-                                                    double *__restrict__ v)
+// ---------------------------------------------------------------------------------
+// k_fast_btran: v = row p of Binv.  A primal step first finishes its ratio test (leaving
+// position p = argmax over the GEMV partials; none = Unbounded, src/simplex.rs:313).
+// grid = ceil(m / 256) workgroups of 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_btran(
+    DzgCtl *ctl, int m, const double *__restrict__ binv, long long ldb,
+    const int *__restrict__ dslot, const int *__restrict__ basis, const int *__restrict__ var_col,
+    const double *__restrict__ U, const double *__restrict__ W, long long ldw,
+    const double *__restrict__ rx_r, const int *__restrict__ rx_k, double *__restrict__ v)
 {
+    __shared__ double s_up[R_];
     if (ctl->status != DZG_RUNNING) return;
-    const double *row = binv + (long long)ctl->leave_pos * m;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < m; c += gridDim.x * blockDim.x)
-        v[c] = row[c];
+    int p;
+    if (ctl->kind == DZG_STEP_PRIMAL) {
+        const DzgCand c = reduce_partials(rx_r, rx_k, DZG_NB_GEMV);
+        if (c.k < 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status = DZG_UNBOUNDED;
+            return;
+        }
+        p = c.k;
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->leave_pos = p;
+    } else {
+        p = ctl->leave_pos;
+    }
+    const int neta = ctl->neta;
+    if (threadIdx.x < R_) s_up[threadIdx.x] = threadIdx.x < neta ? U[(long long)p * R_ + threadIdx.x] : 0.0;
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int slot = dslot[r];
+    const double base = slot >= 0 ? binv[(long long)p * ldb + slot]
+                                  : (var_col[basis[p]] == -1 - r ? 1.0 : 0.0);
+    double acc = 0.0;
+    for (int t = 0; t < neta; ++t) acc = fma(s_up[t], W[(long long)t * ldw + r], acc);
+    v[r] = base - acc;
 }
 
-// w = v / dx_p : the new row p
-__global__ __launch_bounds__(256) void k_fast_newrow(const DzgCtl *ctl, const double *__restrict__ v,
-                                                     const double *__restrict__ dx,
-                                                     double *__restrict__ w, int m)
+// ---------------------------------------------------------------------------------
+// k_fast_pivot: step lengths and the finiteness assert (src/simplex.rs:257-260,:464-468), swap
+// (:239-251), pivot log, then the basis bookkeeping: eta append, compact column append /
+// delete, list of nonbasic structural positions.  One workgroup of 1024.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_fast_pivot(
+    DzgCtl *ctl, int m, int q, const double *__restrict__ x, const double *__restrict__ xbar,
+    const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dx,
+    const double *__restrict__ dz, const double *__restrict__ v, int *basis, int *nonbasis,
+    const int *__restrict__ var_col, double *binv, long long ldb, int *drow, int *dslot,
+    double *U, double *W, long long ldw, int *plist, int *pslot, int *log_kind, int *log_enter,
+    int *log_leave, double *log_mu, long long log_cap)
 {
+    __shared__ int s_ok, s_k, s_ce, s_last;
     if (ctl->status != DZG_RUNNING) return;
-    const double dxp = dx[ctl->leave_pos];
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < m; c += gridDim.x * blockDim.x)
-        w[c] = v[c] / dxp;
-}
-
-// Binv[i][:] -= dx_i * w   (i != p),   Binv[p][:] = w.   One workgroup per 4 rows.
-__global__ __launch_bounds__(256) void k_fast_rank1(const DzgCtl *ctl, double *__restrict__ binv,
-                                                    int m, const double *__restrict__ dx,
-                                                    const double *__restrict__ w)
-{
-    if (ctl->status != DZG_RUNNING) return;
-    const int p = ctl->leave_pos;
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int i = wave_global; i < m; i += nwaves) {
-        double *row = binv + (long long)i * m;
-        const double g = dx[i];
-        if (i == p) {
-            for (int c = lane; c < m; c += 64) row[c] = w[c];
-        } else if ((m & 1) == 0) {
-            for (int c = 2 * lane; c < m; c += 128) {
-                double2_t r = *reinterpret_cast<double2_t *>(row + c);
-                const double2_t ww = *reinterpret_cast<const double2_t *>(w + c);
-                r.x = fma(-g, ww.x, r.x);
-                r.y = fma(-g, ww.y, r.y);
-                *reinterpret_cast<double2_t *>(row + c) = r;
-            }
+    const int tid = threadIdx.x;
+    const int p = ctl->leave_pos, r = ctl->enter_pos;
+    const int neta = ctl->neta;
+    if (tid == 0) {
+        int ok = 1;
+        const double t = dzg_safe_divide(x[p], dx[p], &ok);
+        const double s = dzg_safe_divide(z[r], dz[r], &ok);
+        const double tbar = dzg_safe_divide(xbar[p], dx[p], &ok);
+        const double sbar = dzg_safe_divide(zbar[r], dz[r], &ok);
+        if (neta >= R_) ok = 0; // the host flushes every DZG_RMAX pivots; never reached
+        if (ok) {
+            ctl->t = t;
+            ctl->s = s;
+            ctl->tbar = tbar;
+            ctl->sbar = sbar;
         } else {
-            for (int c = lane; c < m; c += 64) row[c] = fma(-g, w[c], row[c]);
+            ctl->status = DZG_PANIC; // assert in safe_divide, src/simplex.rs:466
+        }
+        s_ok = ok;
+        s_k = ctl->ncompact;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const int vi = basis[p], vj = nonbasis[r];
+    const int ci = var_col[vi], cj = var_col[vj];
+    // ---- eta append: Binv_new = Binv - u v^T, u = (dx - e_p)/dx_p
+    const double dxp = dx[p];
+    double *wt = W + (long long)neta * ldw;
+    for (int i = tid; i < m; i += blockDim.x) {
+        const double d = dx[i];
+        U[(long long)i * R_ + neta] = (i == p ? d - 1.0 : d) / dxp;
+        wt[i] = v[i];
+    }
+    __syncthreads();
+    // ---- a leaving slack makes the column of its row dense: it was e_p
+    if (ci < 0 && tid == 0) {
+        const int k = s_k, rl = -1 - ci;
+        drow[k] = rl;
+        dslot[rl] = k;
+        binv[(long long)p * ldb + k] = 1.0; // columns >= ncompact are kept zero
+        s_k = k + 1;
+    }
+    __syncthreads();
+    // ---- an entering slack makes the column of its row the unit vector e_p again
+    if (cj < 0) {
+        const int re = -1 - cj;
+        if (tid == 0) {
+            s_ce = dslot[re];
+            s_last = s_k - 1;
+        }
+        __syncthreads();
+        const int ce = s_ce, last = s_last;
+        for (int i = tid; i < m; i += blockDim.x) {
+            double *row = binv + (long long)i * ldb;
+            if (ce != last) row[ce] = row[last];
+            row[last] = 0.0;
+        }
+        for (int t = tid; t <= neta; t += blockDim.x) W[(long long)t * ldw + re] = 0.0;
+        __syncthreads();
+        if (tid == 0) {
+            if (ce != last) {
+                const int lr = drow[last];
+                drow[ce] = lr;
+                dslot[lr] = ce;
+            }
+            dslot[re] = -1;
+            s_k = last;
+        }
+    }
+    if (tid != 0) return;
+    // ---- swap, log, counters (single lane)
+    const long long it = ctl->iter;
+    if (it < log_cap) {
+        log_kind[it] = ctl->kind;
+        log_enter[it] = vj;
+        log_leave[it] = vi;
+        log_mu[it] = ctl->mu;
+    }
+    long long s = ctl->nb_struct;
+    ctl->price_bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
+    basis[p] = vj;
+    nonbasis[r] = vi;
+    // nonbasic position r now holds vi instead of vj
+    if (cj >= 0 && ci < 0) { // a structural column left the nonbasic set
+        const int idx = pslot[r], lastpos = plist[s - 1];
+        plist[idx] = lastpos;
+        pslot[lastpos] = idx;
+        pslot[r] = -1;
+        --s;
+    } else if (cj < 0 && ci >= 0) {
+        plist[s] = r;
+        pslot[r] = (int)s;
+        ++s;
+    }
+    ctl->nb_struct = s;
+    ctl->enter_var = vj;
+    ctl->leave_var = vi;
+    ctl->ncompact = s_k;
+    ctl->neta = neta + 1;
+    ctl->iter = it + 1;
+}
+
+// ---------------------------------------------------------------------------------
+// k_fast_update: pivot() x4 (src/simplex.rs:262-265, :410-421) and, on the updated values, the
+// per-workgroup first-pivot candidates of the NEXT iteration (src/simplex.rs:423-437).
+// grid = DZG_NB_UPD workgroups of 256.  only_partials != 0: no update (initial state).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only_partials, double *x,
+                                                     double *xbar, double *z, double *zbar,
+                                                     const double *__restrict__ dx,
+                                                     const double *__restrict__ dz, int m, int q,
+                                                     double *fpx_r, int *fpx_k, double *fpz_r,
+                                                     int *fpz_k)
+{
+    if (ctl->status != DZG_RUNNING) return;
+    const int p = ctl->leave_pos, r = ctl->enter_pos;
+    const double t = ctl->t, s = ctl->s, tbar = ctl->tbar, sbar = ctl->sbar;
+    const int stride = gridDim.x * blockDim.x;
+    DzgCand bx, bz;
+    bx.r = bz.r = 0.0;
+    bx.k = bz.k = -1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        double xi = x[i], xb = xbar[i];
+        if (!only_partials) {
+            const double d = dx[i];
+            const double a = t * d, b = tbar * d;
+            xi = (i == p) ? t : xi - a;
+            xb = (i == p) ? tbar : xb - b;
+            x[i] = xi;
+            xbar[i] = xb;
+        }
+        if (xb > 0.0) {
+            DzgCand c;
+            c.r = -xi / xb;
+            c.k = i;
+            if (c.r == c.r) bx = dzg_better(bx, c);
+        }
+    }
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < q; k += stride) {
+        double zk = z[k], zb = zbar[k];
+        if (!only_partials) {
+            const double d = dz[k];
+            const double a = s * d, b = sbar * d;
+            zk = (k == r) ? s : zk - a;
+            zb = (k == r) ? sbar : zb - b;
+            z[k] = zk;
+            zbar[k] = zb;
+        }
+        if (zb > 0.0) {
+            DzgCand c;
+            c.r = -zk / zb;
+            c.k = k;
+            if (c.r == c.r) bz = dzg_better(bz, c);
+        }
+    }
+    bx = dzg_block_best(bx);
+    bz = dzg_block_best(bz);
+    if (threadIdx.x == 0) {
+        fpx_r[blockIdx.x] = bx.r;
+        fpx_k[blockIdx.x] = bx.k;
+        fpz_r[blockIdx.x] = bz.r;
+        fpz_k[blockIdx.x] = bz.k;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Flush: Binv0[:, 0:k] -= U[:, 0:neta] * Wc,  Wc[t][c] = W[t][drow[c]].
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_gather_w(const DzgCtl *ctl, const double *__restrict__ W,
+                                                       long long ldw, const int *__restrict__ drow,
+                                                       double *__restrict__ Wc)
+{
+    if (ctl->neta <= 0) return;
+    const int k = ctl->ncompact, neta = ctl->neta;
+    const int t = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kpad = (k + 15) & ~15;
+    if (c >= kpad) return;
+    // rows neta..63 and columns k..kpad-1 are zero so the MFMA loop needs no masks on B
+    Wc[(long long)t * ldw + c] = (t < neta && c < k) ? W[(long long)t * ldw + drow[c]] : 0.0;
+}
+
+// One wave owns a 16-row x 64-column strip of Binv0 (4 MFMA tiles side by side) and walks the
+// eta index in steps of 4: D = C - A*B with v_mfma_f64_16x16x4_f64.  Operand lane maps
+// (cdna_hip_programming.md section 3): A[i = l&15][kk = l>>4], B[kk = l>>4][j = l&15],
+// C/D[row = (l>>4) + 4*reg][col = l&15].
+__global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int m,
+                                                         double *__restrict__ binv, long long ldb,
+                                                         const double *__restrict__ U,
+                                                         const double *__restrict__ Wc,
+                                                         long long ldw)
+{
+    const int neta = ctl->neta, k = ctl->ncompact;
+    if (neta <= 0 || k <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64;
+    const int i0 = (blockIdx.y * 4 + wave) * 16;
+    if (c0 >= k || i0 >= m) return;
+    const int li = lane & 15, lk = lane >> 4;
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            acc[j][g] = (row < m && col < k) ? binv[(long long)row * ldb + col] : 0.0;
+        }
+    }
+    const int arow = i0 + li;
+    const double *ua = U + (long long)(arow < m ? arow : 0) * R_;
+    const int ksteps = (neta + 3) >> 2;
+    for (int s = 0; s < ksteps; ++s) {
+        const int t = 4 * s + lk;
+        const double a = (arow < m && t < neta) ? -ua[t] : 0.0;
+        const double *wrow = Wc + (long long)t * ldw + c0 + li; // t < 64 always in range
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double b = wrow[16 * j];
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            if (row < m && col < k) binv[(long long)row * ldb + col] = acc[j][g];
         }
     }
 }
 
-static inline int cap_grid(long long blocks, int cap)
+__global__ void k_fast_flush_done(DzgCtl *ctl)
 {
-    if (blocks < 1) blocks = 1;
-    return (int)(blocks > cap ? cap : blocks);
+    ctl->neta = 0;
 }
 
+__global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, int *dslot,
+                                                   const int *__restrict__ nonbasis,
+                                                   const int *__restrict__ var_col, int *plist,
+                                                   int *pslot)
+{
+    // single workgroup: the structural-position list must be built in position order
+    for (int r = threadIdx.x; r < m; r += blockDim.x) dslot[r] = -1;
+    __shared__ int s_count;
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int k = 0; k < q; ++k) {
+            if (var_col[nonbasis[k]] >= 0) {
+                plist[s] = k;
+                pslot[k] = s;
+                ++s;
+            } else {
+                pslot[k] = -1;
+            }
+        }
+        s_count = s;
+        ctl->ncompact = 0;
+        ctl->neta = 0;
+        ctl->nb_struct = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
 {
-    hipMemsetAsync(d.binv, 0, sizeof(double) * (size_t)d.m * (size_t)d.m, st);
-    hipLaunchKernelGGL(k_fast_init, dim3((d.m + 255) / 256), dim3(256), 0, st, d.binv, d.m, d.basis,
-                       d.var_col);
+    hipMemsetAsync(d.binv, 0, sizeof(double) * (size_t)d.m * (size_t)d.ldb, st);
+    hipMemsetAsync(d.U, 0, sizeof(double) * (size_t)(d.m ? d.m : 1) * R_, st);
+    hipMemsetAsync(d.W, 0, sizeof(double) * (size_t)d.ldw * R_, st);
+    hipMemsetAsync(d.Wc, 0, sizeof(double) * (size_t)d.ldw * R_, st);
+    hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
+    hipLaunchKernelGGL(k_fast_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.dslot, d.nonbasis,
+                       d.var_col, d.plist, d.pslot);
 }
 
-void dzg_launch_fast_ftran(const DzgDev &d, int need_kind, hipStream_t st)
+void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fast_ftran, dim3(cap_grid((d.m + 3) / 4, 2048)), dim3(256), 0, st, d.ctl,
-                       need_kind, d.binv, d.m, d.A, d.lda, d.nonbasis, d.var_col, d.dx);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_fast_select_prep<0>), dim3(R_ + 1), dim3(256), 0, st, d.ctl, d.m, d.A,
+                           d.lda, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.rz_r,
+                           d.rz_k, nrz, d.W, d.ldw, d.drow, d.ag, d.beta, d.eps);
+    else
+        hipLaunchKernelGGL((k_fast_select_prep<1>), dim3(R_ + 1), dim3(256), 0, st, d.ctl, d.m, d.A,
+                           d.lda, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.rz_r,
+                           d.rz_k, nrz, d.W, d.ldw, d.drow, d.ag, d.beta, d.eps);
+}
+
+void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fast_gemv, dim3(DZG_NB_GEMV), dim3(256), 0, st, d.ctl, need_kind, d.m,
+                       d.binv, d.ldb, d.ag, d.U, d.beta, d.A, d.lda, d.basis, d.nonbasis, d.var_col,
+                       d.x, d.xbar, d.dx, d.rx_r, d.rx_k);
 }
 
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fast_btran, dim3(cap_grid((d.m + 255) / 256, 256)), dim3(256), 0, st, d.ctl,
-                       d.binv, d.m, d.v);
+    hipLaunchKernelGGL(k_fast_btran, dim3((d.m + 255) / 256), dim3(256), 0, st, d.ctl, d.m, d.binv,
+                       d.ldb, d.dslot, d.basis, d.var_col, d.U, d.W, d.ldw, d.rx_r, d.rx_k, d.v);
 }
 
-void dzg_launch_fast_update(const DzgDev &d, hipStream_t st)
+void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fast_newrow, dim3(cap_grid((d.m + 255) / 256, 256)), dim3(256), 0, st,
-                       d.ctl, d.v, d.dx, d.w, d.m);
-    hipLaunchKernelGGL(k_fast_rank1, dim3(cap_grid((d.m + 3) / 4, 2048)), dim3(256), 0, st, d.ctl,
-                       d.binv, d.m, d.dx, d.w);
+    hipLaunchKernelGGL(k_fast_pivot, dim3(1), dim3(1024), 0, st, d.ctl, d.m, d.q, d.x, d.xbar, d.z,
+                       d.zbar, d.dx, d.dz, d.v, d.basis, d.nonbasis, d.var_col, d.binv, d.ldb,
+                       d.drow, d.dslot, d.U, d.W, d.ldw, d.plist, d.pslot, d.log_kind, d.log_enter,
+                       d.log_leave, d.log_mu, d.log_cap);
+}
+
+void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fast_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
+                       d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.fpx_r, d.fpx_k, d.fpz_r,
+                       d.fpz_k);
+}
+
+void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
+{
+    const int kmax = d.m; // ncompact <= m; grids cover the worst case, kernels mask by ctl
+    hipLaunchKernelGGL(k_fast_gather_w, dim3((kmax + 15 + 255) / 256, R_), dim3(256), 0, st, d.ctl,
+                       d.W, d.ldw, d.drow, d.Wc);
+    hipLaunchKernelGGL(k_fast_flush_mfma, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
+                       d.ctl, d.m, d.binv, d.ldb, d.U, d.Wc, d.ldw);
+    hipLaunchKernelGGL(k_fast_flush_done, dim3(1), dim3(1), 0, st, d.ctl);
 }

@@ -1,31 +1,45 @@
-// k_price.hip -- launchers of the pricing kernels (kernels: k_price_kernels.h)
+// k_price.hip -- launchers of the pricing kernels (kernels and design notes: k_price_kernels.h)
 #include "k_price_kernels.h"
 
-static void launch(int kernel, const DzgCtl *ctl, const double *A, long long lda, int m, int ncols,
-                   const int *nonbasis, const int *var_col, const double *v, double *dz,
+static int resolve(int kernel) { return kernel == DZG_PRICE_WAVE ? DZG_PRICE_WAVE : DZG_PRICE_SEQ; }
+
+static void launch(int kernel, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
+                   const int *plist, const int *nonbasis, const int *var_col, const double *v,
+                   double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
                    hipStream_t st)
 {
-    if (ncols <= 0) return;
-    if (kernel == DZG_PRICE_AUTO) kernel = DZG_PRICE_SEQ;
-    if (kernel == DZG_PRICE_WAVE) {
-        int blocks = (ncols + 3) / 4;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_price_wave, dim3(blocks), dim3(256), 0, st, ctl, A, lda, m, ncols,
-                           nonbasis, var_col, v, dz);
-    } else {
-        constexpr int C = 32, TR = 128;
-        hipLaunchKernelGGL((k_price_seq<C, TR>), dim3((ncols + C - 1) / C), dim3(256), 0, st, ctl, A,
-                           lda, m, ncols, nonbasis, var_col, v, dz);
-    }
+    if (q <= 0) return;
+    if (resolve(kernel) == DZG_PRICE_WAVE)
+        hipLaunchKernelGGL((k_price_wave2<4>), dim3(DZG_PRICE_WAVE_BLOCKS), dim3(256), 0, st, ctl, A,
+                           lda, m, q, plist, nonbasis, var_col, v, dz, z, zbar, rz_r, rz_k);
+    else
+        hipLaunchKernelGGL((k_price_seq2<16>), dim3(DZG_PRICE_SEQ_BLOCKS), dim3(256), 0, st, ctl, A,
+                           lda, m, q, plist, nonbasis, var_col, v, dz, z, zbar, rz_r, rz_k);
 }
 
+// number of per-workgroup ratio partials the chosen kernel leaves in rz_r / rz_k
+int dzg_price_partials(int kernel)
+{
+    return resolve(kernel) == DZG_PRICE_WAVE ? DZG_PRICE_WAVE_BLOCKS : DZG_PRICE_SEQ_BLOCKS;
+}
+
+// STRICT numerics: every nonbasic position, no fused ratio test
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
 {
-    launch(kernel, d.ctl, d.A, d.lda, d.m, d.q, d.nonbasis, d.var_col, d.v, d.dz, st);
+    launch(kernel, d.ctl, d.A, d.lda, d.m, d.q, nullptr, d.nonbasis, d.var_col, d.v, d.dz, nullptr,
+           nullptr, nullptr, nullptr, st);
+}
+
+// FAST numerics: structural positions from plist, ratio-test partials for the dual step
+void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
+{
+    launch(kernel, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nonbasis, d.var_col, d.v, d.dz, d.z,
+           d.zbar, d.rz_r, d.rz_k, st);
 }
 
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st)
 {
-    launch(kernel, nullptr, A, lda, m, ncols, cols, nullptr, v, out, st);
+    launch(kernel, nullptr, A, lda, m, ncols, nullptr, cols, nullptr, v, out, nullptr, nullptr,
+           nullptr, nullptr, st);
 }

@@ -1,23 +1,29 @@
-// k_price.hip -- the pricing pass  dz = -N^T v  (src/linalg.rs:199-207 neg_t_dot over
-// collect_columns(n), called at src/simplex.rs:235).  This is the HBM-roofline kernel:
+// k_price_kernels.h -- the pricing pass  dz = -N^T v  (src/linalg.rs:199-207 neg_t_dot over
+// collect_columns(n), called at src/simplex.rs:235), fused with the dual-step ratio test
+// (find_second_pivot over z, src/simplex.rs:324,439-461).  This is the HBM-roofline kernel:
 // it streams every nonbasic structural column of A once per iteration (8*m bytes each).
 //
-// Two kernels, same inputs and outputs:
+//  k_price_seq2  SEQUENTIAL-ORDER kernel (default).  Each WAVE owns up to 16 columns.  For a
+//                tile of 128 rows it fetches 16 x 1 KiB column segments with fully coalesced
+//                16-B/lane nontemporal loads (two tiles are kept in flight in registers),
+//                parks them in a wave-private, bank-conflict-free LDS tile next to -v for the
+//                same rows, and lane c then walks column c top to bottom:
+//                    acc = acc + a * (-v)     product and sum rounded separately, rows ascending
+//                which is exactly the reference's summation order, so dz is BIT-IDENTICAL to
+//                neg_t_dot.  No workgroup barrier anywhere: waves drift freely, the serial
+//                chain (~2-3k cycles per tile) hides under the ~6.5k cycles the same tile
+//                needs from HBM.
+//  k_price_wave2 TREE-ORDER kernel.  One wave per column, lane-strided partial sums with
+//                explicit fma, xor-shuffle tree.  A plain streaming reduction, a few percent
+//                faster, not bit-identical to the reference's sums.
 //
-//  k_price_seq  one LANE per column.  A C x TR tile (C columns, TR rows, column segments
-//               of 1 KiB fetched by fully coalesced 16-B/lane loads) is staged in LDS with
-//               a padded, bank-conflict-free column stride, -v for the same rows sits next
-//               to it, and lane c then walks its column top to bottom: acc = acc + a*(-v),
-//               product and sum rounded separately, rows ascending.  That is exactly the
-//               reference's summation order, so dz is BIT-IDENTICAL to neg_t_dot.  The
-//               serial chain costs ~TR*12 cycles per tile against ~6-13k cycles of HBM time
-//               for the same tile, so the kernel stays bandwidth-bound.
+// Work distribution: the engine keeps the list of nonbasic positions that hold a STRUCTURAL
+// variable (plist, maintained by the pivot kernel) and the kernels split exactly those
+// columns evenly over the waves of a fixed grid, so basic columns and slack positions cost no
+// matrix bytes and every CU gets the same share whatever the basis looks like.  Slack
+// positions are unit columns: dz = 0.0 + 1.0 * -v[row].
 //
-//  k_price_wave one WAVE per column, lane-strided partial sums, xor-shuffle tree.  Plain
-//               streaming reduction; sums in a different order (not bit-identical).
-//
-// Column codes: >= 0 structural column index, < 0 unit (slack) column of row -1-code,
-// whose "dot product" is 0.0 + 1.0 * -v[row] and costs no matrix bytes.
+// Column codes: >= 0 structural column index, < 0 unit (slack) column of row -1-code.
 #pragma once
 #include "common.h"
 
@@ -30,199 +36,252 @@ __device__ __forceinline__ int price_code(const int *__restrict__ nonbasis,
     return var_col ? var_col[v] : v;
 }
 
-// ---------------------------------------------------------------------------------
-// k_price_seq<C, TR>: 256 threads, C columns per workgroup, tiles of TR rows.
-// ---------------------------------------------------------------------------------
-template <int C, int TR>
-__global__ __launch_bounds__(256) void k_price_seq(const DzgCtl *ctl, const double *__restrict__ A,
-                                                   long long lda, int m, int ncols,
-                                                   const int *__restrict__ nonbasis,
-                                                   const int *__restrict__ var_col,
-                                                   const double *__restrict__ v,
-                                                   double *__restrict__ dz)
+// ratio-test candidate of one position (src/simplex.rs:449-455): dz / (z + mu*zbar) if > 0
+__device__ __forceinline__ void price_candidate(DzgCand &best, double dzk, int pos, double mu,
+                                                const double *__restrict__ z,
+                                                const double *__restrict__ zbar)
 {
-    static_assert(TR % 128 == 0, "a wave fetches 128 rows (1 KiB) of one column per load");
-    constexpr int PAD = 2;                 // column stride TR+2 doubles: lane c starts 4c banks on
-    constexpr int CH = TR / 128;           // 1-KiB chunks per column and tile
-    constexpr int NL = C * CH / 4;         // loads per thread and tile (4 waves)
-    static_assert(NL >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) double tile[C][TR + PAD];
-    __shared__ __attribute__((aligned(16))) double negv[TR];
-    __shared__ int s_code[C];
-
-    if (ctl && ctl->status != DZG_RUNNING) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos0 = blockIdx.x * C;
-    if (tid < C) s_code[tid] = (pos0 + tid < ncols) ? price_code(nonbasis, var_col, pos0 + tid) : -1;
-    __syncthreads();
-
-    // loader geometry: wave-instruction wi covers column wi / CH, rows (wi % CH)*128 + 2*lane
-    long long goff[NL]; // element offset of this thread's load inside A, or -1: nothing to fetch
-    int lcol[NL], lrow[NL];
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const int wi = l * 4 + wave;
-        lcol[l] = wi / CH;
-        lrow[l] = (wi % CH) * 128 + 2 * lane;
-        const int code = s_code[lcol[l]];
-        goff[l] = (code >= 0) ? (long long)code * lda + lrow[l] : -1;
-    }
-
-    const int ntiles = (m + TR - 1) / TR;
-    double2_t reg[NL];
-    double2_t vreg = {0.0, 0.0};
-
-    auto fetch = [&](int t) {
-        const int row0 = t * TR;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            double2_t val = {0.0, 0.0};
-            // lda is a multiple of 16 and rows >= m are zero-padded, so a 16-B load that
-            // starts below m never leaves the column
-            if (goff[l] >= 0 && row0 + lrow[l] < m)
-                val = *reinterpret_cast<const double2_t *>(A + goff[l] + row0);
-            reg[l] = val;
-        }
-        if (tid < TR / 2) {
-            const int r = row0 + 2 * tid;
-            double2_t vv = {0.0, 0.0};
-            if (r < m) vv.x = v[r];
-            if (r + 1 < m) vv.y = v[r + 1];
-            vreg = vv;
-        }
-    };
-
-    double acc = 0.0; // Iterator::sum identity
-    fetch(0);
-    for (int t = 0; t < ntiles; ++t) {
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-            *reinterpret_cast<double2_t *>(&tile[lcol[l]][lrow[l]]) = reg[l];
-        if (tid < TR / 2) {
-            double2_t nv = {-vreg.x, -vreg.y};
-            *reinterpret_cast<double2_t *>(&negv[2 * tid]) = nv;
-        }
-        __syncthreads();
-        if (t + 1 < ntiles) fetch(t + 1); // in flight while the columns are walked
-        if (tid < C) {
-            const int rows = min(TR, m - t * TR);
-            if (rows == TR) {
-#pragma unroll 8
-                for (int r = 0; r < TR; r += 2) {
-                    const double2_t a = *reinterpret_cast<const double2_t *>(&tile[tid][r]);
-                    const double2_t nv = *reinterpret_cast<const double2_t *>(&negv[r]);
-                    const double p0 = a.x * nv.x;
-                    acc = acc + p0;
-                    const double p1 = a.y * nv.y;
-                    acc = acc + p1;
-                }
-            } else {
-                for (int r = 0; r < rows; ++r) {
-                    const double p = tile[tid][r] * negv[r];
-                    acc = acc + p;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (tid < C && pos0 + tid < ncols) {
-        const int code = s_code[tid];
-        if (code < 0) {
-            const double p = 1.0 * -v[-1 - code];
-            acc = 0.0 + p;
-        }
-        dz[pos0 + tid] = acc;
-    }
+    const double scaled = mu * zbar[pos];
+    const double den = z[pos] + scaled;
+    DzgCand c;
+    c.r = dzk / den;
+    c.k = pos;
+    if (c.r > 0.0) best = dzg_better(best, c);
 }
 
-// ---------------------------------------------------------------------------------
-// k_price_wave: one wave per column, 4 x 16-B loads in flight per lane.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_price_wave(const DzgCtl *ctl, const double *__restrict__ A,
-                                                    long long lda, int m, int ncols,
-                                                    const int *__restrict__ nonbasis,
-                                                    const int *__restrict__ var_col,
-                                                    const double *__restrict__ v,
-                                                    double *__restrict__ dz)
-{
-    if (ctl && ctl->status != DZG_RUNNING) return;
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int m2 = m & ~1;
-    for (int pos = wave_global; pos < ncols; pos += nwaves) {
-        const int code = price_code(nonbasis, var_col, pos);
-        if (code < 0) {
-            if (lane == 0) dz[pos] = 0.0 + 1.0 * -v[-1 - code];
-            continue;
-        }
-        const double *col = A + (long long)code * lda;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int r = 2 * lane;
-        for (; r + 384 < m2; r += 512) {
-            const double2_t c0 = *reinterpret_cast<const double2_t *>(col + r);
-            const double2_t c1 = *reinterpret_cast<const double2_t *>(col + r + 128);
-            const double2_t c2 = *reinterpret_cast<const double2_t *>(col + r + 256);
-            const double2_t c3 = *reinterpret_cast<const double2_t *>(col + r + 384);
-            const double2_t v0 = *reinterpret_cast<const double2_t *>(v + r);
-            const double2_t v1 = *reinterpret_cast<const double2_t *>(v + r + 128);
-            const double2_t v2 = *reinterpret_cast<const double2_t *>(v + r + 256);
-            const double2_t v3 = *reinterpret_cast<const double2_t *>(v + r + 384);
-            a0 = fma(c0.x, v0.x, a0);
-            a1 = fma(c1.x, v1.x, a1);
-            a2 = fma(c2.x, v2.x, a2);
-            a3 = fma(c3.x, v3.x, a3);
-            a0 = fma(c0.y, v0.y, a0);
-            a1 = fma(c1.y, v1.y, a1);
-            a2 = fma(c2.y, v2.y, a2);
-            a3 = fma(c3.y, v3.y, a3);
-        }
-        for (; r < m2; r += 128) {
-            const double2_t c0 = *reinterpret_cast<const double2_t *>(col + r);
-            const double2_t v0 = *reinterpret_cast<const double2_t *>(v + r);
-            a0 = fma(c0.x, v0.x, a0);
-            a0 = fma(c0.y, v0.y, a0);
-        }
-        if (lane == 0 && m2 < m) a1 = fma(col[m2], v[m2], a1);
-        double acc = (a0 + a1) + (a2 + a3);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
-        if (lane == 0) dz[pos] = -acc;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------
-// k_price_wave2<U, VLDS>: one wave per column, U x 16-B loads in flight per lane;
-// VLDS stages v in LDS once per workgroup (m*8 bytes of dynamic LDS) so that the L2
-// only serves the matrix stream.  Columns are dealt to waves round-robin over the grid.
-// ---------------------------------------------------------------------------------
-template <int U, bool VLDS>
-__global__ __launch_bounds__(1024) void k_price_wave2(const DzgCtl *ctl, const double *__restrict__ A,
-                                                      long long lda, int m, int ncols,
+// unit columns: every thread of the grid takes positions pos = tid, tid + nthreads, ...
+__device__ __forceinline__ void price_slack_positions(DzgCand &best, int q,
                                                       const int *__restrict__ nonbasis,
                                                       const int *__restrict__ var_col,
                                                       const double *__restrict__ v,
-                                                      double *__restrict__ dz)
+                                                      double *__restrict__ dz, double mu,
+                                                      const double *__restrict__ z,
+                                                      const double *__restrict__ zbar)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_v[];
-    if (ctl && ctl->status != DZG_RUNNING) return;
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    const int wave_global = blockIdx.x * wpb + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * wpb;
-    const int mpad = (m + 1) & ~1;
-    if (VLDS) {
-        for (int i = threadIdx.x; i < mpad; i += blockDim.x) s_v[i] = (i < m) ? v[i] : 0.0;
-        __syncthreads();
-    }
-    const double *vv = VLDS ? s_v : v; // v has >= 2 zero pad entries past m in global memory
-    for (int pos = wave_global; pos < ncols; pos += nwaves) {
+    const int nthreads = gridDim.x * blockDim.x;
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < q; pos += nthreads) {
         const int code = price_code(nonbasis, var_col, pos);
         if (code < 0) {
-            if (lane == 0) dz[pos] = 0.0 + 1.0 * -v[-1 - code];
-            continue;
+            const double p = 1.0 * -v[-1 - code];
+            const double d = 0.0 + p; // Iterator::sum identity + the single stored entry
+            dz[pos] = d;
+            if (z) price_candidate(best, d, pos, mu, z, zbar);
         }
+    }
+}
+
+__device__ __forceinline__ void price_publish(DzgCand best, double *__restrict__ rz_r,
+                                              int *__restrict__ rz_k)
+{
+    best = dzg_block_best(best);
+    if (rz_r && threadIdx.x == 0) {
+        rz_r[blockIdx.x] = best.r;
+        rz_k[blockIdx.x] = best.k;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_price_seq2<CW>: 4 waves per workgroup, CW columns per wave and pass, tiles of 128 rows.
+// Engine mode: plist != nullptr, count = ctl->nb_struct.  Raw mode (parity tests):
+// plist == nullptr, every position 0..q-1 is a column, codes may be negative.
+// ---------------------------------------------------------------------------------
+template <int CW, int DEPTH = 3, int DBG = 0, bool NT = true>
+__global__ __launch_bounds__(256) void k_price_seq2(
+    const DzgCtl *ctl, const double *__restrict__ A, long long lda, int m, int q,
+    const int *__restrict__ plist, const int *__restrict__ nonbasis,
+    const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
+    const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
+    int *__restrict__ rz_k)
+{
+    constexpr int TR = 128, PAD = 2; // column stride 130 doubles: lane c starts 4c banks on
+    __shared__ __attribute__((aligned(16))) double tile[4][CW][TR + PAD];
+    __shared__ __attribute__((aligned(16))) double negv[4][TR];
+    if (ctl && ctl->status != DZG_RUNNING) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wg = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const double mu = ctl ? ctl->mu : 0.0;
+    DzgCand best;
+    best.r = 0.0;
+    best.k = -1;
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, z, zbar);
+
+    const int count = plist ? (int)ctl->nb_struct : q;
+    const int base = count / nw, rem = count % nw;
+    const int start = wg * base + (wg < rem ? wg : rem);
+    const int cnt = base + (wg < rem ? 1 : 0);
+    const int ntiles = (m + TR - 1) / TR;
+    double(*mytile)[TR + PAD] = tile[wave];
+    double *mynegv = negv[wave];
+
+    for (int c0 = 0; c0 < cnt; c0 += CW) {
+        const int nc = (cnt - c0) < CW ? (cnt - c0) : CW;
+        int mypos = -1, mycode = -1;
+        if (lane < nc) {
+            const int idx = start + c0 + lane;
+            mypos = plist ? plist[idx] : idx;
+            mycode = price_code(nonbasis, var_col, mypos);
+        }
+        // wave-uniform column offsets (scalar registers).  Every load below is issued
+        // unconditionally so that the compiler can count outstanding loads exactly
+        // (s_waitcnt vmcnt(N) with N > 0 keeps the second tile in flight); columns past nc and
+        // unit columns re-read the wave's last valid column (served by L1/L2) and are ignored.
+        int lastcode = 0;
+#pragma unroll
+        for (int l = 0; l < CW; ++l) {
+            const int code_l = __builtin_amdgcn_readlane(mycode, l);
+            if (code_l >= 0) lastcode = code_l;
+        }
+        long long off[CW];
+#pragma unroll
+        for (int l = 0; l < CW; ++l) {
+            const int code_l = __builtin_amdgcn_readlane(mycode, l);
+            off[l] = (long long)(code_l >= 0 ? code_l : lastcode) * lda;
+        }
+        double2_t rg[DEPTH][CW], vg[DEPTH]; // DEPTH tiles in flight, statically indexed
+        double dbg_sink = 0.0;
+        // lda is a multiple of 16 and rows m..lda-1 are zero, v carries 2 zero pads: a 16-B
+        // load that starts below lda (resp. m) stays inside its column (resp. v).  Rows past
+        // the end are clamped to the last pair and zeroed after the load (no branches).
+        const int lastpair = (int)lda - 2;
+        const int lastv = ((m + 1) & ~1) - 2 >= 0 ? ((m + 1) & ~1) - 2 : 0;
+
+        // fetch only issues loads (clamped addresses); the masks are applied in park(), at the
+        // first use, so nothing here waits on a load
+        auto fetch = [&](int t, double2_t(&reg)[CW], double2_t &vreg) {
+            const int row = t * TR + 2 * lane;
+            const int rowc = row < lda ? row : lastpair;
+#pragma unroll
+            for (int l = 0; l < CW; ++l) {
+                const double2_t *gp = reinterpret_cast<const double2_t *>(A + off[l] + rowc);
+                reg[l] = NT ? __builtin_nontemporal_load(gp) : *gp;
+            }
+            vreg = *reinterpret_cast<const double2_t *>(v + (row < m ? row : lastv));
+        };
+        auto park = [&](int t, const double2_t(&reg)[CW], const double2_t &vreg) {
+            if (DBG == 2) { // diagnostic: consume the registers, skip LDS
+#pragma unroll
+                for (int l = 0; l < CW; ++l) dbg_sink += reg[l].x + reg[l].y;
+                return;
+            }
+            const int row = t * TR + 2 * lane;
+            const bool inside = row < lda, vin = row < m;
+            const double2_t zero = {0.0, 0.0};
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int l = 0; l < CW; ++l)
+                *reinterpret_cast<double2_t *>(&mytile[l][2 * lane]) = inside ? reg[l] : zero;
+            const double2_t nv = {-vreg.x, -vreg.y};
+            *reinterpret_cast<double2_t *>(&mynegv[2 * lane]) = vin ? nv : zero;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        double acc = 0.0; // Iterator::sum identity
+        // Every lane walks (lanes past nc walk a duplicate column and are ignored), so the walk
+        // has no divergence.  LDS reads (16 rows of the column + the same rows of -v, a
+        // broadcast) are issued one chunk ahead of the chunk whose products are being chained;
+        // only the 128 additions of a tile form a dependent chain.
+        const double *colp = mytile[lane & (CW - 1)];
+        auto walk = [&](int t) {
+            if (DBG != 0) return;
+            const int row0 = t * TR;
+            const int rows = (m - row0) < TR ? (m - row0) : TR;
+            if (rows == TR) {
+                double2_t buf[2][8], nvb[2][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    buf[0][j] = *reinterpret_cast<const double2_t *>(colp + 2 * j);
+                    nvb[0][j] = *reinterpret_cast<const double2_t *>(mynegv + 2 * j);
+                }
+#pragma unroll
+                for (int c = 0; c < TR / 16; ++c) {
+                    if (c + 1 < TR / 16) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            buf[(c + 1) & 1][j] =
+                                *reinterpret_cast<const double2_t *>(colp + 16 * (c + 1) + 2 * j);
+                            nvb[(c + 1) & 1][j] =
+                                *reinterpret_cast<const double2_t *>(mynegv + 16 * (c + 1) + 2 * j);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const double p0 = buf[c & 1][j].x * nvb[c & 1][j].x;
+                        acc = acc + p0;
+                        const double p1 = buf[c & 1][j].y * nvb[c & 1][j].y;
+                        acc = acc + p1;
+                    }
+                }
+            } else {
+                for (int r = 0; r < rows; ++r) {
+                    const double p = colp[r] * mynegv[r];
+                    acc = acc + p;
+                }
+            }
+        };
+
+        // DEPTH tiles in flight; the steady-state loop has no conditional loads
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d < ntiles ? d : ntiles - 1, rg[d], vg[d]);
+        int t = 0;
+        for (; t + 2 * DEPTH - 1 < ntiles; t += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                park(t + d, rg[d], vg[d]);
+                fetch(t + DEPTH + d, rg[d], vg[d]);
+                walk(t + d);
+            }
+        }
+        // drain: fewer than 2*DEPTH tiles left
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (t + d < ntiles) {
+                park(t + d, rg[d], vg[d]);
+                if (t + DEPTH + d < ntiles) fetch(t + DEPTH + d, rg[d], vg[d]);
+                walk(t + d);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (t + DEPTH + d < ntiles) {
+                park(t + DEPTH + d, rg[d], vg[d]);
+                walk(t + DEPTH + d);
+            }
+        }
+        if (DBG != 0) acc = dbg_sink + mytile[lane & (CW - 1)][lane];
+        if (lane < nc && mycode >= 0) {
+            dz[mypos] = acc;
+            if (z) price_candidate(best, acc, mypos, mu, z, zbar);
+        }
+    }
+    price_publish(best, rz_r, rz_k);
+}
+
+// ---------------------------------------------------------------------------------
+// k_price_wave2<U>: one wave per column, U x 16-B nontemporal loads in flight per lane.
+// ---------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void k_price_wave2(
+    const DzgCtl *ctl, const double *__restrict__ A, long long lda, int m, int q,
+    const int *__restrict__ plist, const int *__restrict__ nonbasis,
+    const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
+    const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
+    int *__restrict__ rz_k)
+{
+    if (ctl && ctl->status != DZG_RUNNING) return;
+    const int lane = threadIdx.x & 63;
+    const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    const double mu = ctl ? ctl->mu : 0.0;
+    DzgCand best;
+    best.r = 0.0;
+    best.k = -1;
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, z, zbar);
+    const int count = plist ? (int)ctl->nb_struct : q;
+    const int mpad = (m + 1) & ~1;
+    for (int idx = wg; idx < count; idx += nw) {
+        const int pos = plist ? plist[idx] : idx;
+        const int code = price_code(nonbasis, var_col, pos);
+        if (code < 0) continue;
         const double *col = A + (long long)code * lda; // rows m..lda-1 are zero
         double acc[U];
 #pragma unroll
@@ -232,9 +291,10 @@ __global__ __launch_bounds__(1024) void k_price_wave2(const DzgCtl *ctl, const d
             double2_t c[U], w[U];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                c[u] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(col + r + 128 * u));
+                c[u] = __builtin_nontemporal_load(
+                    reinterpret_cast<const double2_t *>(col + r + 128 * u));
 #pragma unroll
-            for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const double2_t *>(vv + r + 128 * u);
+            for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const double2_t *>(v + r + 128 * u);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 acc[u] = fma(c[u].x, w[u].x, acc[u]);
@@ -243,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_price_wave2(const DzgCtl *ctl, const d
         }
         for (; r < mpad; r += 128) {
             const double2_t c0 = *reinterpret_cast<const double2_t *>(col + r);
-            const double2_t w0 = *reinterpret_cast<const double2_t *>(vv + r);
+            const double2_t w0 = *reinterpret_cast<const double2_t *>(v + r);
             acc[0] = fma(c0.x, w0.x, acc[0]);
             acc[0] = fma(c0.y, w0.y, acc[0]);
         }
@@ -252,6 +312,13 @@ __global__ __launch_bounds__(1024) void k_price_wave2(const DzgCtl *ctl, const d
         for (int u = 0; u < U; ++u) s += acc[u];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, DZG_WAVE);
-        if (lane == 0) dz[pos] = -s;
+        if (lane == 0) {
+            dz[pos] = -s;
+            if (z) price_candidate(best, -s, pos, mu, z, zbar);
+        }
     }
+    price_publish(best, rz_r, rz_k);
 }
+
+#define DZG_PRICE_SEQ_BLOCKS 256   // x 4 waves: one workgroup per CU
+#define DZG_PRICE_WAVE_BLOCKS 2048 // x 4 waves

@@ -19,7 +19,6 @@ __global__ void k_fill(double *a, size_t n, unsigned long long seed)
     }
 }
 
-// pure read stream: the practical HBM read roofline for this access shape
 template <int U>
 __global__ __launch_bounds__(256) void k_stream(const double *__restrict__ a, size_t n2, double *out)
 {
@@ -42,7 +41,8 @@ int main(int argc, char **argv)
     int m = argc > 1 ? atoi(argv[1]) : 8192;
     int ns = argc > 2 ? atoi(argv[2]) : 16384;
     int reps = argc > 3 ? atoi(argv[3]) : 20;
-    long long lda = (m + 15) / 16 * 16;
+    int ldpad = argc > 4 ? atoi(argv[4]) : 0;
+    long long lda = (m + 15) / 16 * 16 + ldpad;
     size_t na = (size_t)lda * ns;
     double *A, *v, *dz, *ref;
     int *cols;
@@ -60,7 +60,7 @@ int main(int argc, char **argv)
     const double gbytes = 8.0 * m * (double)ns / 1e9;
 
     auto time_it = [&](const char *name, auto launch, bool check) {
-        launch(); // warm
+        launch();
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         for (int r = 0; r < reps; ++r) launch();
@@ -77,23 +77,18 @@ int main(int argc, char **argv)
             maxdiff = 0;
             for (int i = 0; i < ns; ++i) { double d = a[i] - b[i]; if (d < 0) d = -d; if (d > maxdiff) maxdiff = d; }
         }
-        printf("%-28s %9.1f us  %7.1f GB/s  (%.1f%% of 8 TB/s)  maxdiff %.2e\n", name, us, gbytes / (us * 1e-6), 100.0 * gbytes / (us * 1e-6) / 8000.0, maxdiff);
+        printf("%-30s %9.1f us  %7.1f GB/s  (%.1f%% of 8 TB/s)  maxdiff %.2e\n", name, us, gbytes / (us * 1e-6), 100.0 * gbytes / (us * 1e-6) / 8000.0, maxdiff);
         fflush(stdout);
     };
-
-    // reference result
-    hipLaunchKernelGGL((k_price_seq<32, 128>), dim3((ns + 31) / 32), dim3(256), 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, ref);
+#define ARGS nullptr, A, lda, m, ns, nullptr, cols, nullptr, v
+    hipLaunchKernelGGL((k_price_seq2<16>), dim3(256), dim3(256), 0, 0, ARGS, ref, nullptr, nullptr, nullptr, nullptr);
     CK(hipDeviceSynchronize());
-
     time_it("stream U=4 (2048 blk)", [&] { hipLaunchKernelGGL((k_stream<4>), dim3(2048), dim3(256), 0, 0, A, na / 2, dz); }, false);
-    time_it("stream U=8 (2048 blk)", [&] { hipLaunchKernelGGL((k_stream<8>), dim3(2048), dim3(256), 0, 0, A, na / 2, dz); }, false);
-    time_it("stream U=8 (4096 blk)", [&] { hipLaunchKernelGGL((k_stream<8>), dim3(4096), dim3(256), 0, 0, A, na / 2, dz); }, false);
-#define SEQ(C, TR) time_it("seq<" #C "," #TR ">", [&] { hipLaunchKernelGGL((k_price_seq<C, TR>), dim3((ns + C - 1) / C), dim3(256), 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, dz); }, true)
-    SEQ(32, 128); SEQ(32, 256); SEQ(16, 256); SEQ(64, 128); SEQ(16, 512); SEQ(16, 128); SEQ(8, 512);
-    time_it("wave (v0, 2048x256)", [&] { hipLaunchKernelGGL(k_price_wave, dim3(2048), dim3(256), 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, dz); }, true);
-#define WAVE2(U, VL, BLK, THR) time_it("wave2<" #U "," #VL "> " #BLK "x" #THR, [&] { hipLaunchKernelGGL((k_price_wave2<U, VL>), dim3(BLK), dim3(THR), VL ? (size_t)(m + 2) * 8 : 0, 0, nullptr, A, lda, m, ns, cols, nullptr, v, dz); }, true)
-    WAVE2(4, false, 2048, 256); WAVE2(8, false, 2048, 256); WAVE2(8, false, 1024, 512);
-    WAVE2(4, true, 512, 1024); WAVE2(8, true, 512, 1024); WAVE2(8, true, 256, 1024); WAVE2(4, true, 512, 512);
-    WAVE2(2, true, 512, 1024); WAVE2(16, false, 2048, 256);
+#define SEQ2(CW, BLK) time_it("seq2<" #CW "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
+    SEQ2(16, 256); SEQ2(8, 512);
+#define SEQ2D(CW, DEP, DBG, NT, BLK) time_it("seq2<" #CW "," #DEP "," #DBG "," #NT "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW, DEP, DBG, NT>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
+    SEQ2D(16, 2, 0, true, 256); SEQ2D(16, 3, 0, true, 256); SEQ2D(16, 4, 0, true, 256); SEQ2D(8, 4, 0, true, 512); SEQ2D(8, 6, 0, true, 512); SEQ2D(16, 3, 1, true, 256);
+#define WAVE2(U, BLK) time_it("wave2<" #U "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_wave2<U>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
+    WAVE2(4, 2048); WAVE2(4, 4096);
     return 0;
 }
