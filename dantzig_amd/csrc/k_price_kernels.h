@@ -95,10 +95,10 @@ __global__ __launch_bounds__(256) void k_price_seq2(
 {
     constexpr int TR = 128, PAD = 2; // column stride 130 doubles: lane c starts 4c banks on
     __shared__ __attribute__((aligned(16))) double tile[4][CW][TR + PAD];
-    __shared__ __attribute__((aligned(16))) double negv[4][TR];
     if (ctl && ctl->status != DZG_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wg = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int nw = gridDim.x * 4;
+    const int wg = blockIdx.x * 4 + wave;
     const double mu = ctl ? ctl->mu : 0.0;
     DzgCand best;
     best.r = 0.0;
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(256) void k_price_seq2(
     const int cnt = base + (wg < rem ? 1 : 0);
     const int ntiles = (m + TR - 1) / TR;
     double(*mytile)[TR + PAD] = tile[wave];
-    double *mynegv = negv[wave];
 
     for (int c0 = 0; c0 < cnt; c0 += CW) {
         const int nc = (cnt - c0) < CW ? (cnt - c0) : CW;
@@ -139,6 +138,7 @@ __global__ __launch_bounds__(256) void k_price_seq2(
         }
         double2_t rg[DEPTH][CW], vg[DEPTH]; // DEPTH tiles in flight, statically indexed
         double dbg_sink = 0.0;
+        long long cyc_park = 0, cyc_fetch = 0, cyc_walk = 0; // DBG == 4 only
         // lda is a multiple of 16 and rows m..lda-1 are zero, v carries 2 zero pads: a 16-B
         // load that starts below lda (resp. m) stays inside its column (resp. v).  Rows past
         // the end are clamped to the last pair and zeroed after the load (no branches).
@@ -157,6 +157,10 @@ __global__ __launch_bounds__(256) void k_price_seq2(
             }
             vreg = *reinterpret_cast<const double2_t *>(v + (row < m ? row : lastv));
         };
+        // park: lane holds rows (2*lane, 2*lane+1) of every column of the tile, and the same two
+        // rows of v.  It forms the PRODUCTS a * (-v) here, with all 64 lanes busy (one rounding,
+        // exactly the reference's `val * -v[i]`), and parks the products in LDS; the serial
+        // walk then only reads and adds.
         auto park = [&](int t, const double2_t(&reg)[CW], const double2_t &vreg) {
             if (DBG == 2) { // diagnostic: consume the registers, skip LDS
 #pragma unroll
@@ -164,57 +168,50 @@ __global__ __launch_bounds__(256) void k_price_seq2(
                 return;
             }
             const int row = t * TR + 2 * lane;
-            const bool inside = row < lda, vin = row < m;
+            const bool inside = row < lda && row < m + 1; // rows >= m hold zeros or padding
+            const double nv0 = -vreg.x, nv1 = -vreg.y;    // v carries zero pads past m
             const double2_t zero = {0.0, 0.0};
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int l = 0; l < CW; ++l)
-                *reinterpret_cast<double2_t *>(&mytile[l][2 * lane]) = inside ? reg[l] : zero;
-            const double2_t nv = {-vreg.x, -vreg.y};
-            *reinterpret_cast<double2_t *>(&mynegv[2 * lane]) = vin ? nv : zero;
+            for (int l = 0; l < CW; ++l) {
+                double2_t pr;
+                pr.x = reg[l].x * nv0;
+                pr.y = reg[l].y * nv1;
+                *reinterpret_cast<double2_t *>(&mytile[l][2 * lane]) = inside ? pr : zero;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
         double acc = 0.0; // Iterator::sum identity
-        // Every lane walks (lanes past nc walk a duplicate column and are ignored), so the walk
-        // has no divergence.  LDS reads (16 rows of the column + the same rows of -v, a
-        // broadcast) are issued one chunk ahead of the chunk whose products are being chained;
-        // only the 128 additions of a tile form a dependent chain.
+        // walk: lane c adds the products of column c top to bottom -- the only serial part.
+        // LDS reads run one 16-row chunk ahead of the additions.
         const double *colp = mytile[lane & (CW - 1)];
         auto walk = [&](int t) {
-            if (DBG != 0) return;
+            if (DBG != 0 && DBG != 4) return;
             const int row0 = t * TR;
             const int rows = (m - row0) < TR ? (m - row0) : TR;
-            if (rows == TR) {
-                double2_t buf[2][8], nvb[2][8];
+            if (lane < CW) {
+                if (rows == TR) {
+                    double2_t buf[2][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    buf[0][j] = *reinterpret_cast<const double2_t *>(colp + 2 * j);
-                    nvb[0][j] = *reinterpret_cast<const double2_t *>(mynegv + 2 * j);
-                }
+                    for (int j = 0; j < 8; ++j)
+                        buf[0][j] = *reinterpret_cast<const double2_t *>(colp + 2 * j);
 #pragma unroll
-                for (int c = 0; c < TR / 16; ++c) {
-                    if (c + 1 < TR / 16) {
+                    for (int c = 0; c < TR / 16; ++c) {
+                        if (c + 1 < TR / 16) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                buf[(c + 1) & 1][j] = *reinterpret_cast<const double2_t *>(
+                                    colp + 16 * (c + 1) + 2 * j);
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            buf[(c + 1) & 1][j] =
-                                *reinterpret_cast<const double2_t *>(colp + 16 * (c + 1) + 2 * j);
-                            nvb[(c + 1) & 1][j] =
-                                *reinterpret_cast<const double2_t *>(mynegv + 16 * (c + 1) + 2 * j);
+                            acc = acc + buf[c & 1][j].x;
+                            acc = acc + buf[c & 1][j].y;
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const double p0 = buf[c & 1][j].x * nvb[c & 1][j].x;
-                        acc = acc + p0;
-                        const double p1 = buf[c & 1][j].y * nvb[c & 1][j].y;
-                        acc = acc + p1;
-                    }
-                }
-            } else {
-                for (int r = 0; r < rows; ++r) {
-                    const double p = colp[r] * mynegv[r];
-                    acc = acc + p;
+                } else {
+                    for (int r = 0; r < rows; ++r) acc = acc + colp[r];
                 }
             }
         };
@@ -226,9 +223,24 @@ __global__ __launch_bounds__(256) void k_price_seq2(
         for (; t + 2 * DEPTH - 1 < ntiles; t += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
-                park(t + d, rg[d], vg[d]);
-                fetch(t + DEPTH + d, rg[d], vg[d]);
-                walk(t + d);
+                if (DBG == 4) {
+                    const long long s0 = __builtin_amdgcn_s_memtime();
+                    park(t + d, rg[d], vg[d]);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    const long long s1 = __builtin_amdgcn_s_memtime();
+                    fetch(t + DEPTH + d, rg[d], vg[d]);
+                    const long long s2 = __builtin_amdgcn_s_memtime();
+                    walk(t + d);
+                    asm volatile("" ::"v"(acc));
+                    const long long s3 = __builtin_amdgcn_s_memtime();
+                    cyc_park += s1 - s0;
+                    cyc_fetch += s2 - s1;
+                    cyc_walk += s3 - s2;
+                } else {
+                    park(t + d, rg[d], vg[d]);
+                    fetch(t + DEPTH + d, rg[d], vg[d]);
+                    walk(t + d);
+                }
             }
         }
         // drain: fewer than 2*DEPTH tiles left
@@ -247,7 +259,12 @@ __global__ __launch_bounds__(256) void k_price_seq2(
                 walk(t + DEPTH + d);
             }
         }
-        if (DBG != 0) acc = dbg_sink + mytile[lane & (CW - 1)][lane];
+        if (DBG != 0 && DBG != 4) acc = dbg_sink + mytile[lane & (CW - 1)][lane];
+        if (DBG == 4 && lane == 0) { // diagnostic build only: cycles per segment, per wave
+            dz[q + 3 * wg + 0] = (double)cyc_park;
+            dz[q + 3 * wg + 1] = (double)cyc_fetch;
+            dz[q + 3 * wg + 2] = (double)cyc_walk;
+        }
         if (lane < nc && mycode >= 0) {
             dz[mypos] = acc;
             if (z) price_candidate(best, acc, mypos, mu, z, zbar);
