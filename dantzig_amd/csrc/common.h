@@ -33,7 +33,8 @@ struct DzgCtl {
     // fast numerics: compact basis inverse + pending eta file
     int ncompact;        // dense columns of Binv0 in compact storage ("k")
     int neta;            // pending rank-1 updates not yet folded into Binv0
-    int pad0, pad1;
+    int enter_code;      // column code of the entering variable (saves two dependent loads)
+    int pad1;
 };
 
 // Partial-reduction fan-in sizes of the FAST pipeline (fixed grids => fixed counts)
@@ -135,7 +136,7 @@ struct DzgDev {
     long long ldb;
     int *drow;         // [m] constraint row of compact column c
     int *dslot;        // [m] compact column of constraint row r, or -1 (unit column)
-    double *U;         // [m][DZG_RMAX] eta columns, row-major
+    double *U;         // [DZG_RMAX][ldw] eta columns u_t (each contiguous)
     double *W;         // [DZG_RMAX][ldw] eta rows (each W_t contiguous)
     long long ldw;
     double *Wc;        // [DZG_RMAX][ldw] W gathered to compact coordinates (flush scratch)

@@ -278,7 +278,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         d.ldw = ((long long)m + 15) / 16 * 16 + 64;
         TRY(dev_alloc(s, &d.binv, (size_t)(m ? m : 1) * (size_t)d.ldb));
         TRY(dev_alloc(s, &d.drow, (size_t)m)); TRY(dev_alloc(s, &d.dslot, (size_t)m));
-        TRY(dev_alloc(s, &d.U, (size_t)(m ? m : 1) * DZG_RMAX));
+        TRY(dev_alloc(s, &d.U, (size_t)d.ldw * DZG_RMAX));
         TRY(dev_alloc(s, &d.W, (size_t)d.ldw * DZG_RMAX));
         TRY(dev_alloc(s, &d.Wc, (size_t)d.ldw * DZG_RMAX));
         TRY(dev_alloc(s, &d.ag, (size_t)m + 2)); TRY(dev_alloc(s, &d.beta, (size_t)DZG_RMAX));

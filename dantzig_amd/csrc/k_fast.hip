@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
     }
     // ---- FTRAN preparation for the entering variable
     const int code = var_col[nonbasis[epos]];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
     const int neta = ctl->neta, k = ctl->ncompact;
     const int b = blockIdx.x;
     if (b < R_) {
@@ -181,7 +182,7 @@ template <int LPR>
 __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int m, int k, int neta,
                                           int code, const double *__restrict__ binv,
                                           long long ldb, const double *__restrict__ ag,
-                                          const double *__restrict__ U,
+                                          const double *__restrict__ U, long long ldu,
                                           const double *__restrict__ beta,
                                           const double *__restrict__ A, long long lda,
                                           const int *__restrict__ basis,
@@ -221,8 +222,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
                 a0 = fma(r0.y, g0.y, a0);
             }
             acc = a0 + a1;
-            const double *ui = U + (long long)i * R_;
-            for (int t = sub; t < neta; t += LPR) acc = fma(-ui[t], beta[t], acc);
+            for (int t = sub; t < neta; t += LPR) acc = fma(-U[(long long)t * ldu + i], beta[t], acc);
         }
 #pragma unroll
         for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
@@ -247,23 +247,24 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
 
 __global__ __launch_bounds__(256) void k_fast_gemv(
     const DzgCtl *ctl, int need_kind, int m, const double *__restrict__ binv, long long ldb,
-    const double *__restrict__ ag, const double *__restrict__ U, const double *__restrict__ beta,
-    const double *__restrict__ A, long long lda, const int *__restrict__ basis,
+    const double *__restrict__ ag, const double *__restrict__ U, long long ldu,
+    const double *__restrict__ beta, const double *__restrict__ A, long long lda,
+    const int *__restrict__ basis,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
     double *__restrict__ rx_r, int *__restrict__ rx_k)
 {
     if (ctl->status != DZG_RUNNING || ctl->kind != need_kind) return;
     const int k = ctl->ncompact, neta = ctl->neta;
-    const int code = var_col[nonbasis[ctl->enter_pos]];
+    const int code = ctl->enter_code;
     DzgCand best;
     best.r = 0.0;
     best.k = -1;
     if (k > 512)
-        gemv_rows<64>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, beta, A, lda, basis,
+        gemv_rows<64>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, A, lda, basis,
                       var_col, x, xbar, dx, best);
     else
-        gemv_rows<16>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, beta, A, lda, basis,
+        gemv_rows<16>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, A, lda, basis,
                       var_col, x, xbar, dx, best);
     if (need_kind == DZG_STEP_PRIMAL) {
         best = dzg_block_best(best);
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
 __global__ __launch_bounds__(256) void k_fast_btran(
     DzgCtl *ctl, int m, const double *__restrict__ binv, long long ldb,
     const int *__restrict__ dslot, const int *__restrict__ basis, const int *__restrict__ var_col,
-    const double *__restrict__ U, const double *__restrict__ W, long long ldw,
+    const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
     const double *__restrict__ rx_r, const int *__restrict__ rx_k, double *__restrict__ v)
 {
     __shared__ double s_up[R_];
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void k_fast_btran(
         p = ctl->leave_pos;
     }
     const int neta = ctl->neta;
-    if (threadIdx.x < R_) s_up[threadIdx.x] = threadIdx.x < neta ? U[(long long)p * R_ + threadIdx.x] : 0.0;
+    if (threadIdx.x < R_) s_up[threadIdx.x] = threadIdx.x < neta ? U[(long long)threadIdx.x * ldu + p] : 0.0;
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
@@ -322,7 +323,8 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dx,
     const double *__restrict__ dz, const double *__restrict__ v, int *basis, int *nonbasis,
     const int *__restrict__ var_col, double *binv, long long ldb, int *drow, int *dslot,
-    double *U, double *W, long long ldw, int *plist, int *pslot, int *log_kind, int *log_enter,
+    double *U, long long ldu, double *W, long long ldw, int *plist, int *pslot, int *log_kind,
+    int *log_enter,
     int *log_leave, double *log_mu, long long log_cap)
 {
     __shared__ int s_ok, s_k, s_ce, s_last;
@@ -353,11 +355,12 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const int vi = basis[p], vj = nonbasis[r];
     const int ci = var_col[vi], cj = var_col[vj];
     // ---- eta append: Binv_new = Binv - u v^T, u = (dx - e_p)/dx_p
-    const double dxp = dx[p];
+    const double rdxp = 1.0 / dx[p];
     double *wt = W + (long long)neta * ldw;
+    double *ut = U + (long long)neta * ldu; // eta t is one contiguous row of U and one of W
     for (int i = tid; i < m; i += blockDim.x) {
         const double d = dx[i];
-        U[(long long)i * R_ + neta] = (i == p ? d - 1.0 : d) / dxp;
+        ut[i] = (i == p ? d - 1.0 : d) * rdxp;
         wt[i] = v[i];
     }
     __syncthreads();
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256) void k_fast_gather_w(const DzgCtl *ctl, const 
 // C/D[row = (l>>4) + 4*reg][col = l&15].
 __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int m,
                                                          double *__restrict__ binv, long long ldb,
-                                                         const double *__restrict__ U,
+                                                         const double *__restrict__ U, long long ldu,
                                                          const double *__restrict__ Wc,
                                                          long long ldw)
 {
@@ -536,11 +539,11 @@ __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int 
         }
     }
     const int arow = i0 + li;
-    const double *ua = U + (long long)(arow < m ? arow : 0) * R_;
+    const int arowc = arow < m ? arow : 0;
     const int ksteps = (neta + 3) >> 2;
     for (int s = 0; s < ksteps; ++s) {
         const int t = 4 * s + lk;
-        const double a = (arow < m && t < neta) ? -ua[t] : 0.0;
+        const double a = (arow < m && t < neta) ? -U[(long long)t * ldu + arowc] : 0.0;
         const double *wrow = Wc + (long long)t * ldw + c0 + li; // t < 64 always in range
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
 {
     hipMemsetAsync(d.binv, 0, sizeof(double) * (size_t)d.m * (size_t)d.ldb, st);
-    hipMemsetAsync(d.U, 0, sizeof(double) * (size_t)(d.m ? d.m : 1) * R_, st);
+    hipMemsetAsync(d.U, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.W, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.Wc, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
@@ -618,21 +621,21 @@ void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, hipStream_t
 void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_gemv, dim3(DZG_NB_GEMV), dim3(256), 0, st, d.ctl, need_kind, d.m,
-                       d.binv, d.ldb, d.ag, d.U, d.beta, d.A, d.lda, d.basis, d.nonbasis, d.var_col,
+                       d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.basis, d.nonbasis, d.var_col,
                        d.x, d.xbar, d.dx, d.rx_r, d.rx_k);
 }
 
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_btran, dim3((d.m + 255) / 256), dim3(256), 0, st, d.ctl, d.m, d.binv,
-                       d.ldb, d.dslot, d.basis, d.var_col, d.U, d.W, d.ldw, d.rx_r, d.rx_k, d.v);
+                       d.ldb, d.dslot, d.basis, d.var_col, d.U, d.ldw, d.W, d.ldw, d.rx_r, d.rx_k, d.v);
 }
 
 void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_pivot, dim3(1), dim3(1024), 0, st, d.ctl, d.m, d.q, d.x, d.xbar, d.z,
                        d.zbar, d.dx, d.dz, d.v, d.basis, d.nonbasis, d.var_col, d.binv, d.ldb,
-                       d.drow, d.dslot, d.U, d.W, d.ldw, d.plist, d.pslot, d.log_kind, d.log_enter,
+                       d.drow, d.dslot, d.U, d.ldw, d.W, d.ldw, d.plist, d.pslot, d.log_kind, d.log_enter,
                        d.log_leave, d.log_mu, d.log_cap);
 }
 
@@ -649,6 +652,6 @@ void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_fast_gather_w, dim3((kmax + 15 + 255) / 256, R_), dim3(256), 0, st, d.ctl,
                        d.W, d.ldw, d.drow, d.Wc);
     hipLaunchKernelGGL(k_fast_flush_mfma, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
-                       d.ctl, d.m, d.binv, d.ldb, d.U, d.Wc, d.ldw);
+                       d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
     hipLaunchKernelGGL(k_fast_flush_done, dim3(1), dim3(1), 0, st, d.ctl);
 }
