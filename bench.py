@@ -56,6 +56,51 @@ def cpu_baseline(sample_rows: int, sample_cols: int, seed: int, pivots: int, row
     }
 
 
+def pmc_traffic(args) -> dict | None:
+    """HBM bytes per launch of the pricing kernel from the rocprofv3 PMC counters, collected in
+    two separate child runs (FETCH_SIZE and WRITE_SIZE do not fit one pass) BEFORE this process
+    touches the GPU.  Units are KiB; on gfx950 FETCH_SIZE reports exactly half the bytes of a
+    wide coalesced streaming read (MI355X_MICROARCH.md, HBM), so the fetch side is doubled."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    per_launch = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = tempfile.mkdtemp(prefix="dzg_pmc_", dir="/tmp")
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "20",
+                   "--rows", str(args.rows), "--cols", str(args.cols), "--seed", str(args.seed),
+                   "--price", args.price, "--no-cpu-baseline", "--no-pmc-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=240, check=True)
+            total, n = 0.0, 0
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row["Counter_Name"] == counter and "k_price_" in row["Kernel_Name"]:
+                            total += float(row["Counter_Value"])
+                            n += 1
+            shutil.rmtree(out, ignore_errors=True)
+            if n == 0:
+                return None
+            per_launch[counter] = total / n * 1024.0
+    except Exception as exc:  # the profiler is optional: report null rather than fail the bench
+        print(f"pmc traffic unavailable: {exc}", file=sys.stderr)
+        return None
+    fetch = 2.0 * per_launch["FETCH_SIZE"]
+    return {"bytes_per_launch": fetch + per_launch["WRITE_SIZE"],
+            "fetch_bytes_corrected": fetch, "write_bytes": per_launch["WRITE_SIZE"],
+            "note": "rocprofv3 --pmc, separate passes; FETCH_SIZE x2 (gfx950), KiB units"}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +112,7 @@ def main() -> int:
     ap.add_argument("--price", choices=["auto", "seq", "wave"], default="auto")
     ap.add_argument("--numerics", choices=["fast", "strict"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc-traffic", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
     ap.add_argument("--cpu-sample-pivots", type=int, default=40)
     args = ap.parse_args()
@@ -81,6 +127,8 @@ def main() -> int:
         from dantzig_amd import sharded  # column-sharded path
 
         return sharded.bench_main(args, rank, world, local_rank)
+
+    traffic = None if args.no_pmc_traffic else pmc_traffic(args)  # children first: no GPU state yet
 
     import torch
 
@@ -145,7 +193,8 @@ def main() -> int:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic["bytes_per_launch"] if traffic else None,
+            "traffic_detail": traffic,
             "avg_launch_us": 1e3 * price_ms / max(price_launches, 1),
             "launches": price_launches,
             "algorithmic_bytes_per_launch": price_bytes / max(price_launches, 1),
