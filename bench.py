@@ -113,6 +113,8 @@ def main() -> int:
     ap.add_argument("--numerics", choices=["fast", "strict"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc-traffic", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the column-sharded RCCL path even with one rank (rehearsal)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
     ap.add_argument("--cpu-sample-pivots", type=int, default=40)
     args = ap.parse_args()
@@ -123,19 +125,18 @@ def main() -> int:
     if args.gpus != world and world > 1:
         print(f"--gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
         return 2
-    if world > 1:
-        from dantzig_amd import sharded  # column-sharded path
+    if world > 1 or args.force_sharded:
+        from dantzig_amd import sharded  # column-sharded path, native RCCL loop
 
         return sharded.bench_main(args, rank, world, local_rank)
 
     traffic = None if args.no_pmc_traffic else pmc_traffic(args)  # children first: no GPU state yet
 
-    import torch
-
     from dantzig_amd import _ffi, core
 
+    # one HIP runtime per process: the library's.  dzg_solver_run returns after synchronising
+    # its stream, which brackets the timed region the way torch.cuda.synchronize() would.
     _ffi.require_gpu()
-    torch.cuda.set_device(0)
     t_gen = time.perf_counter()
     a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
     lp = core.CoreLP.from_inequality_form(a, b, c)
@@ -149,11 +150,9 @@ def main() -> int:
 
     status = solver.run(args.warmup) if args.warmup > 0 else "iter_limit"
     r0 = solver.result(log=False)
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     if status == "iter_limit":
         status = solver.run(args.steps)
-    torch.cuda.synchronize()
     t1 = time.perf_counter()
     r1 = solver.result(log=False)
     solver.close()

@@ -34,7 +34,11 @@ struct DzgCtl {
     int ncompact;        // dense columns of Binv0 in compact storage ("k")
     int neta;            // pending rank-1 updates not yet folded into Binv0
     int enter_code;      // column code of the entering variable (saves two dependent loads)
-    int pad1;
+    int enter_src;       // sharded: rank whose exchange record carries the entering column
+    // sharded: z, zbar, dz of the entering position as published by its owner
+    double zr, zbar_r, dz_r;
+    int use_record;      // 1: k_fast_pivot takes zr/zbar_r/dz_r instead of its local z arrays
+    int pad2;
 };
 
 // Partial-reduction fan-in sizes of the FAST pipeline (fixed grids => fixed counts)
@@ -152,7 +156,23 @@ struct DzgDev {
     int *piv;     // m
     double *urow, *krow, *lcol; // m each
     double eps;
+    // column sharding (world > 1): this rank holds structural columns [col0, col1)
+    int col0, col1, rank, world;
+    long long xstride;   // exchange record stride in doubles
 };
+
+#ifdef __HIPCC__
+// column of the entering variable: the local matrix (single GPU) or the winner's exchange
+// record (sharded).  code < 0 (slack) has no stored column.
+__device__ __forceinline__ const double *dzg_enter_col(const DzgCtl *ctl, int code,
+                                                       const double *A, long long lda, int col0,
+                                                       const double *xrecv, long long xstride)
+{
+    if (code < 0) return nullptr;
+    if (xrecv) return xrecv + (long long)ctl->enter_src * xstride + 8;
+    return A + (long long)(code - col0) * lda;
+}
+#endif
 
 // k_vector.hip
 void dzg_launch_status(const DzgDev &d, hipStream_t st);
@@ -182,9 +202,12 @@ void dzg_launch_lu_raw(int n, double *lu, double *lt, int *piv, double *urow, do
 
 // k_fast.hip
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st);
-void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, hipStream_t st);
-void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, hipStream_t st);
+void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,
+                                 hipStream_t st);
+void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, hipStream_t st);
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st);
 void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st);
 void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st);
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st);
+void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
+void dzg_launch_shard_decide(const DzgDev &d, int mode, const double *xrecv, hipStream_t st);

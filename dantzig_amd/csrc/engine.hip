@@ -6,6 +6,8 @@
 // enqueues `poll_interval` iterations back to back and reads the status word once per
 // batch.  STRICT numerics needs O(m) launches per iteration anyway and reads the step kind
 // after the status kernel to launch only the solves that iteration uses.
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -77,12 +79,16 @@ struct dzg_solver {
     dzg_opts opts{};
     int numerics = DZG_NUMERICS_FAST;
     hipStream_t st = nullptr;
+    bool own_stream = true;
     DzgCtl *h_ctl = nullptr; // pinned
     std::vector<void *> allocs;
     std::vector<double> c_host;
     double constant = 0.0;
     double solve_ms = 0.0;
     int since_flush = 0; // iterations enqueued since the eta file was last folded into Binv0
+    // column sharding
+    void *comm = nullptr;                  // ncclComm_t
+    double *xsend = nullptr, *xrecv1 = nullptr, *xrecv2 = nullptr;
     // profiling
     std::vector<hipEvent_t> ev; // [batch slot][class][2]
     double kernel_ms[DZG_K_COUNT] = {};
@@ -130,13 +136,49 @@ static int validate(const dzg_lp *lp, std::string &why)
     return 1;
 }
 
+// ---- RCCL, loaded lazily: single-GPU users never need librccl ------------------------
+namespace {
+struct NcclUniqueId { char internal[128]; };
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclUniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    if (r.handle || r.ok) return r;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return r;
+    r.GetUniqueId = (int (*)(NcclUniqueId *))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void **, int, NcclUniqueId, int))dlsym(r.handle, "ncclCommInitRank");
+    r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.handle, "ncclAllGather");
+    r.CommDestroy = (int (*)(void *))dlsym(r.handle, "ncclCommDestroy");
+    r.GetErrorString = (const char *(*)(int))dlsym(r.handle, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
+    return r;
+}
+const int kNcclFloat64 = 8;
+} // namespace
+
+static void shard_comm_destroy(dzg_solver *s);
+
 extern "C" void dzg_solver_destroy(dzg_solver *s)
 {
     if (!s) return;
+    shard_comm_destroy(s);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     for (void *p : s->allocs) hipFree(p);
     if (s->h_ctl) hipHostFree(s->h_ctl);
-    if (s->st) hipStreamDestroy(s->st);
+    if (s->st && s->own_stream) hipStreamDestroy(s->st);
     delete s;
 }
 
@@ -162,7 +204,12 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     dzg_solver *s = new dzg_solver();
     s->opts = o;
     struct Guard { dzg_solver *s; ~Guard() { if (s) dzg_solver_destroy(s); } } guard{s};
-    HIP_OK(hipStreamCreate(&s->st));
+    if (o.stream) {
+        s->st = (hipStream_t)o.stream;
+        s->own_stream = false;
+    } else {
+        HIP_OK(hipStreamCreate(&s->st));
+    }
     HIP_OK(hipHostMalloc((void **)&s->h_ctl, sizeof(DzgCtl)));
 
     DzgDev &d = s->d;
@@ -171,31 +218,45 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     d.lda = ((long long)m + 15) / 16 * 16;
     if (d.lda == 0) d.lda = 16;
     d.eps = o.epsilon;
+    d.world = o.world > 1 ? o.world : 1;
+    d.rank = d.world > 1 ? o.rank : 0;
+    d.col0 = 0;
+    d.col1 = ns;
+    if (d.world > 1) {
+        if (o.rank < 0 || o.rank >= o.world || o.col_begin < 0 || o.col_end > ns ||
+            o.col_begin > o.col_end)
+            return fail(DZG_E_ARG, "opts.rank / col_begin / col_end");
+        d.col0 = (int)o.col_begin;
+        d.col1 = (int)o.col_end;
+    }
+    d.xstride = 8 + ((long long)m + 7) / 8 * 8;
+    const int nloc = d.col1 - d.col0; // structural columns resident on this device
+    const double *a_host = lp->a ? lp->a + (size_t)d.col0 * (size_t)lp->lda : nullptr;
 
     // --- constraint matrix: column-major, zero-padded to lda rows (16-B aligned columns)
     double *A = nullptr;
-    TRY(dev_alloc(s, &A, (size_t)d.lda * (size_t)(ns ? ns : 1)));
-    HIP_OK(hipMemsetAsync(A, 0, sizeof(double) * (size_t)d.lda * (size_t)(ns ? ns : 1), s->st));
-    if (ns > 0 && m > 0) {
+    TRY(dev_alloc(s, &A, (size_t)d.lda * (size_t)(nloc ? nloc : 1)));
+    HIP_OK(hipMemsetAsync(A, 0, sizeof(double) * (size_t)d.lda * (size_t)(nloc ? nloc : 1), s->st));
+    if (nloc > 0 && m > 0) {
         // the reference's CSC drops exact zeros (src/linalg.rs:261), so -0.0 entries act as +0.0
         bool has_negzero = false;
-        for (int64_t j = 0; j < ns && !has_negzero; ++j)
+        for (int64_t j = 0; j < nloc && !has_negzero; ++j)
             for (int64_t i = 0; i < m; ++i) {
-                const double val = lp->a[j * lp->lda + i];
+                const double val = a_host[j * lp->lda + i];
                 if (val == 0.0 && std::signbit(val)) { has_negzero = true; break; }
             }
         if (!has_negzero) {
-            HIP_OK(hipMemcpy2DAsync(A, sizeof(double) * d.lda, lp->a, sizeof(double) * lp->lda,
-                                    sizeof(double) * m, ns, hipMemcpyHostToDevice, s->st));
+            HIP_OK(hipMemcpy2DAsync(A, sizeof(double) * d.lda, a_host, sizeof(double) * lp->lda,
+                                    sizeof(double) * m, nloc, hipMemcpyHostToDevice, s->st));
         } else {
-            std::vector<double> tmp((size_t)m * ns);
-            for (int64_t j = 0; j < ns; ++j)
+            std::vector<double> tmp((size_t)m * nloc);
+            for (int64_t j = 0; j < nloc; ++j)
                 for (int64_t i = 0; i < m; ++i) {
-                    const double val = lp->a[j * lp->lda + i];
+                    const double val = a_host[j * lp->lda + i];
                     tmp[(size_t)(j * m + i)] = (val == 0.0) ? 0.0 : val;
                 }
             HIP_OK(hipMemcpy2DAsync(A, sizeof(double) * d.lda, tmp.data(), sizeof(double) * m,
-                                    sizeof(double) * m, ns, hipMemcpyHostToDevice, s->st));
+                                    sizeof(double) * m, nloc, hipMemcpyHostToDevice, s->st));
             HIP_OK(hipStreamSynchronize(s->st));
         }
     }
@@ -253,6 +314,8 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                       : o.numerics;
     if (s->numerics != DZG_NUMERICS_STRICT && s->numerics != DZG_NUMERICS_FAST)
         return fail(DZG_E_ARG, "opts.numerics");
+    if (d.world > 1 && s->numerics != DZG_NUMERICS_FAST)
+        return fail(DZG_E_ARG, "column sharding needs FAST numerics");
     TRY(dev_alloc(s, &d.ctl, 1));
     DzgCtl c0;
     std::memset(&c0, 0, sizeof(c0));
@@ -338,10 +401,10 @@ static void enqueue_fast_iteration(dzg_solver *s, int slot)
     Prof pf{s, slot};
     const int pk = price_kernel_for(s);
     pf.begin(DZG_K_STATUS);
-    dzg_launch_fast_select_prep(d, 0, 0, st); // status() + FTRAN prep of a primal step
+    dzg_launch_fast_select_prep(d, 0, 0, nullptr, st); // status() + FTRAN prep of a primal step
     pf.end(DZG_K_STATUS);
     pf.begin(DZG_K_FTRAN);
-    dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, st); // primal step: dx first (+ ratio partials)
+    dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, nullptr, st); // primal step: dx first (+ ratio partials)
     pf.end(DZG_K_FTRAN);
     pf.begin(DZG_K_BTRAN);
     dzg_launch_fast_btran(d, st); // (primal: finishes the ratio test) v = row p of Binv
@@ -350,8 +413,8 @@ static void enqueue_fast_iteration(dzg_solver *s, int slot)
     dzg_launch_price_fast(d, pk, st); // dz (+ dual ratio partials)
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_RATIO);
-    dzg_launch_fast_select_prep(d, 1, dzg_price_partials(pk), st); // dual: ratio test + prep
-    dzg_launch_fast_gemv(d, DZG_STEP_DUAL, st);                    // dual step: dx last
+    dzg_launch_fast_select_prep(d, 1, dzg_price_partials(pk), nullptr, st); // dual: ratio + prep
+    dzg_launch_fast_gemv(d, DZG_STEP_DUAL, nullptr, st);                    // dual step: dx last
     pf.end(DZG_K_RATIO);
     pf.begin(DZG_K_UPDATE);
     dzg_launch_fast_pivot(d, st);
@@ -438,10 +501,8 @@ static int run_strict(dzg_solver *s)
     return 0;
 }
 
-extern "C" int dzg_solver_run(dzg_solver *s, int64_t max_new_iters)
+static int set_budget(dzg_solver *s, int64_t max_new_iters)
 {
-    if (!s) return fail(DZG_E_ARG, "solver is NULL");
-    HIP_OK(hipSetDevice(s->opts.device));
     TRY(read_ctl(s));
     DzgCtl *h = s->h_ctl;
     if (h->status != DZG_RUNNING && h->status != DZG_ITER_LIMIT) return h->status;
@@ -454,6 +515,192 @@ extern "C" int dzg_solver_run(dzg_solver *s, int64_t max_new_iters)
     HIP_OK(hipMemcpyAsync(&s->d.ctl->status, &h->status, sizeof(int), hipMemcpyHostToDevice, s->st));
     HIP_OK(hipMemcpyAsync(&s->d.ctl->iter_stop, &h->iter_stop, sizeof(long long), hipMemcpyHostToDevice, s->st));
     HIP_OK(hipStreamSynchronize(s->st));
+    return DZG_RUNNING;
+}
+
+extern "C" int dzg_solver_set_budget(dzg_solver *s, int64_t max_new_iters)
+{
+    if (!s) return fail(DZG_E_ARG, "solver is NULL");
+    HIP_OK(hipSetDevice(s->opts.device));
+    return set_budget(s, max_new_iters);
+}
+
+extern "C" int dzg_solver_poll(dzg_solver *s, int32_t *status, int64_t *iterations)
+{
+    if (!s) return fail(DZG_E_ARG, "solver is NULL");
+    HIP_OK(hipSetDevice(s->opts.device));
+    TRY(read_ctl(s));
+    HIP_OK(hipGetLastError());
+    if (status) *status = s->h_ctl->status;
+    if (iterations) *iterations = s->h_ctl->iter;
+    return 0;
+}
+
+// ---- column sharding: three enqueue-only phases per iteration (dantzig_amd.h) ---------
+extern "C" int64_t dzg_shard_record_doubles(const dzg_solver *s) { return s ? s->d.xstride : 0; }
+
+extern "C" int dzg_shard_phase1(dzg_solver *s, double *send_dev)
+{
+    if (!s || !send_dev || s->numerics != DZG_NUMERICS_FAST) return fail(DZG_E_ARG, "phase1");
+    dzg_launch_shard_propose(s->d, 0, 0, send_dev, s->st);
+    return 0;
+}
+
+extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *send_dev)
+{
+    if (!s || !recv_dev || !send_dev || s->numerics != DZG_NUMERICS_FAST)
+        return fail(DZG_E_ARG, "phase2");
+    const DzgDev &d = s->d;
+    hipStream_t st = s->st;
+    const int pk = price_kernel_for(s);
+    dzg_launch_shard_decide(d, 0, recv_dev, st);           // merge + status()
+    dzg_launch_fast_select_prep(d, 2, 0, recv_dev, st);    // primal: FTRAN prep from the record
+    dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, recv_dev, st);
+    dzg_launch_fast_btran(d, st);
+    dzg_launch_price_fast(d, pk, st);                      // owned columns only
+    dzg_launch_shard_propose(d, 1, dzg_price_partials(pk), send_dev, st);
+    return 0;
+}
+
+extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
+{
+    if (!s || !recv_dev || s->numerics != DZG_NUMERICS_FAST) return fail(DZG_E_ARG, "phase3");
+    const DzgDev &d = s->d;
+    hipStream_t st = s->st;
+    dzg_launch_shard_decide(d, 1, recv_dev, st);           // merge: entering position / z values
+    dzg_launch_fast_select_prep(d, 3, 0, recv_dev, st);    // dual: FTRAN prep from the record
+    dzg_launch_fast_gemv(d, DZG_STEP_DUAL, recv_dev, st);
+    dzg_launch_fast_pivot(d, st);
+    dzg_launch_fast_update(d, 0, st);
+    if (++s->since_flush >= DZG_RMAX) {
+        dzg_launch_fast_flush(d, st);
+        s->since_flush = 0;
+    }
+    return 0;
+}
+
+static void shard_comm_destroy(dzg_solver *s)
+{
+    if (s->comm && rccl().ok) rccl().CommDestroy(s->comm);
+    s->comm = nullptr;
+}
+
+extern "C" void *dzg_solver_stream(dzg_solver *s) { return s ? (void *)s->st : nullptr; }
+
+extern "C" int dzg_comm_unique_id(void *unique_id_128)
+{
+    if (!unique_id_128) return fail(DZG_E_ARG, "unique_id is NULL");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(DZG_E_DEVICE, "librccl could not be loaded");
+    NcclUniqueId id;
+    const int rc = r.GetUniqueId(&id);
+    if (rc != 0) return fail(DZG_E_DEVICE, std::string("ncclGetUniqueId: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
+    std::memcpy(unique_id_128, &id, sizeof(id));
+    return 0;
+}
+
+static int shard_buffers(dzg_solver *s)
+{
+    if (s->xsend) return 0;
+    const size_t n = (size_t)s->d.xstride;
+    TRY(dev_alloc(s, &s->xsend, n));
+    TRY(dev_alloc(s, &s->xrecv1, n * (size_t)s->d.world));
+    TRY(dev_alloc(s, &s->xrecv2, n * (size_t)s->d.world));
+    HIP_OK(hipMemsetAsync(s->xsend, 0, sizeof(double) * n, s->st));
+    HIP_OK(hipMemsetAsync(s->xrecv1, 0, sizeof(double) * n * s->d.world, s->st));
+    HIP_OK(hipMemsetAsync(s->xrecv2, 0, sizeof(double) * n * s->d.world, s->st));
+    return 0;
+}
+
+extern "C" int dzg_shard_comm_init(dzg_solver *s, const void *unique_id_128)
+{
+    if (!s || !unique_id_128 || s->d.world < 1) return fail(DZG_E_ARG, "comm_init");
+    HIP_OK(hipSetDevice(s->opts.device));
+    Rccl &r = rccl();
+    if (!r.ok) return fail(DZG_E_DEVICE, "librccl could not be loaded");
+    NcclUniqueId id;
+    std::memcpy(&id, unique_id_128, sizeof(id));
+    const int rc = r.CommInitRank(&s->comm, s->d.world, id, s->d.rank);
+    if (rc != 0) return fail(DZG_E_DEVICE, std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
+    return shard_buffers(s);
+}
+
+extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
+{
+    if (!s || !s->comm) return fail(DZG_E_ARG, "dzg_shard_comm_init first");
+    HIP_OK(hipSetDevice(s->opts.device));
+    {
+        const int rc0 = set_budget(s, max_new_iters);
+        if (rc0 != DZG_RUNNING) return rc0;
+    }
+    Rccl &r = rccl();
+    const size_t n = (size_t)s->d.xstride;
+    auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int b = 0; b < s->opts.poll_interval; ++b) {
+            TRY(dzg_shard_phase1(s, s->xsend));
+            if (r.AllGather(s->xsend, s->xrecv1, n, kNcclFloat64, s->comm, s->st) != 0)
+                return fail(DZG_E_DEVICE, "ncclAllGather (exchange 1)");
+            TRY(dzg_shard_phase2(s, s->xrecv1, s->xsend));
+            if (r.AllGather(s->xsend, s->xrecv2, n, kNcclFloat64, s->comm, s->st) != 0)
+                return fail(DZG_E_DEVICE, "ncclAllGather (exchange 2)");
+            TRY(dzg_shard_phase3(s, s->xrecv2));
+        }
+        TRY(read_ctl(s));
+        HIP_OK(hipGetLastError());
+        if (s->h_ctl->status != DZG_RUNNING) break;
+    }
+    s->solve_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return s->h_ctl->status;
+}
+
+extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t max_new_iters)
+{
+    if (!sv || world < 1) return fail(DZG_E_ARG, "lockstep");
+    for (int r = 0; r < world; ++r) {
+        if (!sv[r] || sv[r]->d.world != world || sv[r]->d.rank != r || sv[r]->st != sv[0]->st)
+            return fail(DZG_E_ARG, "lockstep: solvers must be ranks 0..world-1 on one stream");
+        TRY(shard_buffers(sv[r]));
+        const int rc0 = set_budget(sv[r], max_new_iters);
+        if (rc0 != DZG_RUNNING) return rc0;
+    }
+    hipStream_t st = sv[0]->st;
+    const size_t nb = sizeof(double) * (size_t)sv[0]->d.xstride;
+    auto exchange = [&](bool second) -> int {
+        for (int dst = 0; dst < world; ++dst)
+            for (int src = 0; src < world; ++src) {
+                double *to = (second ? sv[dst]->xrecv2 : sv[dst]->xrecv1) + (size_t)src * sv[0]->d.xstride;
+                HIP_OK(hipMemcpyAsync(to, sv[src]->xsend, nb, hipMemcpyDeviceToDevice, st));
+            }
+        return 0;
+    };
+    for (;;) {
+        for (int b = 0; b < sv[0]->opts.poll_interval; ++b) {
+            for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));
+            TRY(exchange(false));
+            for (int r = 0; r < world; ++r) TRY(dzg_shard_phase2(sv[r], sv[r]->xrecv1, sv[r]->xsend));
+            TRY(exchange(true));
+            for (int r = 0; r < world; ++r) TRY(dzg_shard_phase3(sv[r], sv[r]->xrecv2));
+        }
+        for (int r = 0; r < world; ++r) TRY(read_ctl(sv[r]));
+        HIP_OK(hipGetLastError());
+        for (int r = 1; r < world; ++r)
+            if (sv[r]->h_ctl->status != sv[0]->h_ctl->status || sv[r]->h_ctl->iter != sv[0]->h_ctl->iter)
+                return fail(DZG_E_DEVICE, "lockstep: ranks diverged");
+        if (sv[0]->h_ctl->status != DZG_RUNNING) break;
+    }
+    return sv[0]->h_ctl->status;
+}
+
+extern "C" int dzg_solver_run(dzg_solver *s, int64_t max_new_iters)
+{
+    if (!s) return fail(DZG_E_ARG, "solver is NULL");
+    if (s->d.world > 1) return fail(DZG_E_ARG, "a sharded solver is driven through dzg_shard_run");
+    HIP_OK(hipSetDevice(s->opts.device));
+    {
+        const int rc0 = set_budget(s, max_new_iters);
+        if (rc0 != DZG_RUNNING) return rc0;
+    }
     auto t0 = std::chrono::steady_clock::now();
     int rc = s->numerics == DZG_NUMERICS_FAST ? run_fast(s) : run_strict(s);
     auto t1 = std::chrono::steady_clock::now();

@@ -77,7 +77,8 @@ __device__ __forceinline__ double block_sum(double x)
 // ---------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fast_select_prep(
-    DzgCtl *ctl, int m, const double *__restrict__ A, long long lda,
+    DzgCtl *ctl, int m, const double *__restrict__ A, long long lda, int col0,
+    const double *__restrict__ xrecv, long long xstride, int need_kind,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ fpx_r, const int *__restrict__ fpx_k,
     const double *__restrict__ fpz_r, const int *__restrict__ fpz_k,
@@ -132,6 +133,9 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         }
         if (kind != DZG_STEP_PRIMAL) return;
         epos = cj.k;
+    } else if (MODE == 2) { // sharded: k_shard_decide already published the selection
+        if (ctl->kind != need_kind) return;
+        epos = ctl->enter_pos;
     } else {
         if (ctl->kind != DZG_STEP_DUAL) return;
         const DzgCand c = reduce_partials(rz_r, rz_k, nrz);
@@ -143,8 +147,9 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_pos = epos;
     }
     // ---- FTRAN preparation for the entering variable
-    const int code = var_col[nonbasis[epos]];
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
+    const int code = MODE == 2 ? ctl->enter_code : var_col[nonbasis[epos]];
+    if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
+    const double *a = dzg_enter_col(ctl, code, A, lda, col0, xrecv, xstride);
     const int neta = ctl->neta, k = ctl->ncompact;
     const int b = blockIdx.x;
     if (b < R_) {
@@ -154,7 +159,6 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
             if (threadIdx.x == 0) beta[b] = wt[-1 - code];
             return;
         }
-        const double *a = A + (long long)code * lda;
         double acc = 0.0;
         for (int i = threadIdx.x; i < m; i += blockDim.x) acc = fma(wt[i], a[i], acc);
         acc = block_sum(acc);
@@ -164,7 +168,6 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
             const int rr = -1 - code;
             for (int c = threadIdx.x; c < k; c += blockDim.x) ag[c] = (drow[c] == rr) ? 1.0 : 0.0;
         } else {
-            const double *a = A + (long long)code * lda;
             for (int c = threadIdx.x; c < k; c += blockDim.x) ag[c] = a[drow[c]];
         }
         // pad to a multiple of 2 so the GEMV can read 16 B at a time
@@ -184,7 +187,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
                                           long long ldb, const double *__restrict__ ag,
                                           const double *__restrict__ U, long long ldu,
                                           const double *__restrict__ beta,
-                                          const double *__restrict__ A, long long lda,
+                                          const double *__restrict__ acolp,
                                           const int *__restrict__ basis,
                                           const int *__restrict__ var_col,
                                           const double *__restrict__ x,
@@ -230,7 +233,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
             const int bc = var_col[basis[i]];
             if (bc < 0) { // position i holds the slack of row rr: unit column contributes a_j[rr]
                 const int rr = -1 - bc;
-                acc += code >= 0 ? A[(long long)code * lda + rr] : ((-1 - code) == rr ? 1.0 : 0.0);
+                acc += code >= 0 ? acolp[rr] : ((-1 - code) == rr ? 1.0 : 0.0);
             }
             dx[i] = acc;
             if (need_kind == DZG_STEP_PRIMAL) {
@@ -248,8 +251,8 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
 __global__ __launch_bounds__(256) void k_fast_gemv(
     const DzgCtl *ctl, int need_kind, int m, const double *__restrict__ binv, long long ldb,
     const double *__restrict__ ag, const double *__restrict__ U, long long ldu,
-    const double *__restrict__ beta, const double *__restrict__ A, long long lda,
-    const int *__restrict__ basis,
+    const double *__restrict__ beta, const double *__restrict__ A, long long lda, int col0,
+    const double *__restrict__ xrecv, long long xstride, const int *__restrict__ basis,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
     double *__restrict__ rx_r, int *__restrict__ rx_k)
@@ -257,14 +260,15 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
     if (ctl->status != DZG_RUNNING || ctl->kind != need_kind) return;
     const int k = ctl->ncompact, neta = ctl->neta;
     const int code = ctl->enter_code;
+    const double *acolp = dzg_enter_col(ctl, code, A, lda, col0, xrecv, xstride);
     DzgCand best;
     best.r = 0.0;
     best.k = -1;
     if (k > 512)
-        gemv_rows<64>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, A, lda, basis,
+        gemv_rows<64>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
                       var_col, x, xbar, dx, best);
     else
-        gemv_rows<16>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, A, lda, basis,
+        gemv_rows<16>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
                       var_col, x, xbar, dx, best);
     if (need_kind == DZG_STEP_PRIMAL) {
         best = dzg_block_best(best);
@@ -323,8 +327,8 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dx,
     const double *__restrict__ dz, const double *__restrict__ v, int *basis, int *nonbasis,
     const int *__restrict__ var_col, double *binv, long long ldb, int *drow, int *dslot,
-    double *U, long long ldu, double *W, long long ldw, int *plist, int *pslot, int *log_kind,
-    int *log_enter,
+    double *U, long long ldu, double *W, long long ldw, int *plist, int *pslot, int col0, int col1,
+    int *log_kind, int *log_enter,
     int *log_leave, double *log_mu, long long log_cap)
 {
     __shared__ int s_ok, s_k, s_ce, s_last;
@@ -334,10 +338,14 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const int neta = ctl->neta;
     if (tid == 0) {
         int ok = 1;
+        // sharded: z, zbar, dz of the entering position come from its owner's exchange record
+        const bool rec = ctl->use_record != 0;
+        const double zr = rec ? ctl->zr : z[r], zbr = rec ? ctl->zbar_r : zbar[r];
+        const double dzr = rec ? ctl->dz_r : dz[r];
         const double t = dzg_safe_divide(x[p], dx[p], &ok);
-        const double s = dzg_safe_divide(z[r], dz[r], &ok);
+        const double s = dzg_safe_divide(zr, dzr, &ok);
         const double tbar = dzg_safe_divide(xbar[p], dx[p], &ok);
-        const double sbar = dzg_safe_divide(zbar[r], dz[r], &ok);
+        const double sbar = dzg_safe_divide(zbr, dzr, &ok);
         if (neta >= R_) ok = 0; // the host flushes every DZG_RMAX pivots; never reached
         if (ok) {
             ctl->t = t;
@@ -412,14 +420,15 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     ctl->price_bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
     basis[p] = vj;
     nonbasis[r] = vi;
-    // nonbasic position r now holds vi instead of vj
-    if (cj >= 0 && ci < 0) { // a structural column left the nonbasic set
+    // nonbasic position r now holds vi instead of vj; the list only tracks OWNED columns
+    const bool own_j = cj >= col0 && cj < col1, own_i = ci >= col0 && ci < col1;
+    if (own_j && !own_i) { // an owned structural column left the nonbasic set
         const int idx = pslot[r], lastpos = plist[s - 1];
         plist[idx] = lastpos;
         pslot[lastpos] = idx;
         pslot[r] = -1;
         --s;
-    } else if (cj < 0 && ci >= 0) {
+    } else if (!own_j && own_i) {
         plist[s] = r;
         pslot[r] = (int)s;
         ++s;
@@ -441,8 +450,10 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
                                                      double *xbar, double *z, double *zbar,
                                                      const double *__restrict__ dx,
                                                      const double *__restrict__ dz, int m, int q,
-                                                     double *fpx_r, int *fpx_k, double *fpz_r,
-                                                     int *fpz_k)
+                                                     const int *__restrict__ nonbasis,
+                                                     const int *__restrict__ var_col, int col0,
+                                                     int col1, int sharded, double *fpx_r,
+                                                     int *fpx_k, double *fpz_r, int *fpz_k)
 {
     if (ctl->status != DZG_RUNNING) return;
     const int p = ctl->leave_pos, r = ctl->enter_pos;
@@ -478,7 +489,12 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
             z[k] = zk;
             zbar[k] = zb;
         }
-        if (zb > 0.0) {
+        bool mine = true; // sharded: z is only maintained for slack positions and owned columns
+        if (sharded) {
+            const int code = var_col[nonbasis[k]];
+            mine = code < 0 || (code >= col0 && code < col1);
+        }
+        if (mine && zb > 0.0) {
             DzgCand c;
             c.r = -zk / zb;
             c.k = k;
@@ -569,7 +585,7 @@ __global__ void k_fast_flush_done(DzgCtl *ctl)
 __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, int *dslot,
                                                    const int *__restrict__ nonbasis,
                                                    const int *__restrict__ var_col, int *plist,
-                                                   int *pslot)
+                                                   int *pslot, int col0, int col1)
 {
     // single workgroup: the structural-position list must be built in position order
     for (int r = threadIdx.x; r < m; r += blockDim.x) dslot[r] = -1;
@@ -577,7 +593,8 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
     if (threadIdx.x == 0) {
         int s = 0;
         for (int k = 0; k < q; ++k) {
-            if (var_col[nonbasis[k]] >= 0) {
+            const int code = var_col[nonbasis[k]];
+            if (code >= col0 && code < col1) {
                 plist[s] = k;
                 pslot[k] = s;
                 ++s;
@@ -593,6 +610,175 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
 }
 
 // ---------------------------------------------------------------------------------
+// Column sharding (one process per GPU).  Every rank runs the same O(m k) basis work on
+// replicated x, dx, v, Binv; only the matrix, z and the pricing pass are split by column
+// ownership.  Two exchanges per iteration, each one record per rank (layout: dantzig_amd.h).
+// The merges below are deterministic (largest ratio, lowest GLOBAL position) and every rank
+// sees the same records in the same order, so all ranks take identical decisions.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int shard_merge(const double *__restrict__ xrecv, long long xstride,
+                                           int world, DzgCand &win)
+{
+    int w = -1;
+    win.r = 0.0;
+    win.k = -1;
+    for (int r = 0; r < world; ++r) {
+        const double *rec = xrecv + (long long)r * xstride;
+        DzgCand c;
+        c.r = rec[0];
+        c.k = (int)rec[1];
+        if (c.k < 0 || c.r != c.r) continue;
+        if (win.k < 0 || c.r > win.r || (c.r == win.r && c.k < win.k)) {
+            win = c;
+            w = r;
+        }
+    }
+    return w;
+}
+
+// MODE 0: propose the first-pivot candidate of the z side (before status()).
+// MODE 1: after pricing -- dual: propose the ratio-test candidate; primal: the owner of the
+//         entering position publishes its z, zbar, dz.
+// grid = 1 + ceil(m / 256): workgroup 0 writes the header, the others copy the column.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shard_propose(
+    const DzgCtl *ctl, int m, const double *__restrict__ A, long long lda, int col0, int col1,
+    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dz,
+    const double *__restrict__ pr, const int *__restrict__ pk, int np, double *__restrict__ rec)
+{
+    if (ctl->status != DZG_RUNNING) return;
+    double ratio = 0.0;
+    int pos = -1;
+    bool want_column = true;
+    if (MODE == 1 && ctl->kind == DZG_STEP_PRIMAL) {
+        const int code = ctl->enter_code;
+        if (code < 0 || (code >= col0 && code < col1)) {
+            pos = ctl->enter_pos;
+            ratio = 1.0;
+        }
+        want_column = false; // FTRAN already happened
+    } else {
+        const DzgCand c = reduce_partials(pr, pk, np);
+        pos = c.k;
+        ratio = c.r;
+    }
+    const int code = pos >= 0 ? var_col[nonbasis[pos]] : -1;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            rec[0] = ratio;
+            rec[1] = (double)pos;
+            rec[2] = pos >= 0 ? z[pos] : 0.0;
+            rec[3] = pos >= 0 ? zbar[pos] : 0.0;
+            rec[4] = (MODE == 1 && pos >= 0) ? dz[pos] : 0.0;
+            rec[5] = (double)code;
+            rec[6] = rec[7] = 0.0;
+        }
+        return;
+    }
+    if (!want_column || code < 0) return;
+    const int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+    if (i < m) rec[8 + i] = A[(long long)(code - col0) * lda + i];
+}
+
+// MODE 0: merge the proposals, then status() exactly as k_fast_select_prep<0>.
+// MODE 1: merge the second exchange: dual -> entering position (none = Infeasible), its
+//         column and z, zbar, dz; primal -> z, zbar, dz of the entering position.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shard_decide(DzgCtl *ctl, int m, int world,
+                                                      const double *__restrict__ xrecv,
+                                                      long long xstride,
+                                                      const double *__restrict__ fpx_r,
+                                                      const int *__restrict__ fpx_k, double eps)
+{
+    if (ctl->status != DZG_RUNNING) return;
+    const bool lead = threadIdx.x == 0;
+    if (MODE == 0) {
+        DzgCand cj;
+        const int w = shard_merge(xrecv, xstride, world, cj);
+        const DzgCand ci = reduce_partials(fpx_r, fpx_k, DZG_NB_UPD);
+        if (!lead) return;
+        int kind;
+        double mu;
+        if (cj.k >= 0 && ci.k >= 0) {
+            const double primal = ci.r, dual = cj.r;
+            if (primal <= eps && dual <= eps) {
+                ctl->status = DZG_OPTIMAL;
+                return;
+            }
+            if (primal < dual) {
+                kind = DZG_STEP_PRIMAL;
+                mu = dual;
+            } else {
+                kind = DZG_STEP_DUAL;
+                mu = primal;
+            }
+        } else if (cj.k >= 0) {
+            kind = DZG_STEP_PRIMAL;
+            mu = cj.r;
+        } else if (ci.k >= 0) {
+            kind = DZG_STEP_DUAL;
+            mu = ci.r;
+        } else {
+            ctl->status = DZG_PANIC;
+            return;
+        }
+        if (ctl->iter >= ctl->iter_stop) {
+            ctl->status = DZG_ITER_LIMIT;
+            return;
+        }
+        if (m == 0) {
+            ctl->status = DZG_PANIC;
+            return;
+        }
+        ctl->kind = kind;
+        ctl->mu = mu;
+        ctl->use_record = 0;
+        if (kind == DZG_STEP_PRIMAL) {
+            ctl->enter_pos = cj.k;
+            ctl->leave_pos = -1;
+            ctl->enter_code = (int)xrecv[(long long)w * xstride + 5];
+            ctl->enter_src = w;
+        } else {
+            ctl->leave_pos = ci.k;
+            ctl->enter_pos = -1;
+        }
+    } else {
+        if (!lead) return;
+        if (ctl->kind == DZG_STEP_DUAL) {
+            DzgCand c;
+            const int w = shard_merge(xrecv, xstride, world, c);
+            if (w < 0) {
+                ctl->status = DZG_INFEASIBLE; // src/simplex.rs:325
+                return;
+            }
+            const double *rec = xrecv + (long long)w * xstride;
+            ctl->enter_pos = c.k;
+            ctl->enter_code = (int)rec[5];
+            ctl->enter_src = w;
+            ctl->zr = rec[2];
+            ctl->zbar_r = rec[3];
+            ctl->dz_r = rec[4];
+            ctl->use_record = 1;
+        } else {
+            const int want = ctl->enter_pos;
+            int w = -1;
+            for (int r = 0; r < world && w < 0; ++r)
+                if ((int)xrecv[(long long)r * xstride + 1] == want) w = r;
+            if (w < 0) {
+                ctl->status = DZG_PANIC; // no rank owns the entering position: cannot happen
+                return;
+            }
+            const double *rec = xrecv + (long long)w * xstride;
+            ctl->zr = rec[2];
+            ctl->zbar_r = rec[3];
+            ctl->dz_r = rec[4];
+            ctl->use_record = 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
@@ -603,26 +789,31 @@ void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
     hipMemsetAsync(d.Wc, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
     hipLaunchKernelGGL(k_fast_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.dslot, d.nonbasis,
-                       d.var_col, d.plist, d.pslot);
+                       d.var_col, d.plist, d.pslot, d.col0, d.col1);
 }
 
-void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, hipStream_t st)
+void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,
+                                 hipStream_t st)
 {
+    // mode 0: status + primal prep, 1: dual ratio + prep, 2/3: sharded prep of a primal/dual step
+#define SEL_ARGS(need) d.ctl, d.m, d.A, d.lda, d.col0, xrecv, d.xstride, need, d.nonbasis, d.var_col,    \
+                       d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.rz_r, d.rz_k, nrz, d.W, d.ldw, d.drow, d.ag,  \
+                       d.beta, d.eps
     if (mode == 0)
-        hipLaunchKernelGGL((k_fast_select_prep<0>), dim3(R_ + 1), dim3(256), 0, st, d.ctl, d.m, d.A,
-                           d.lda, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.rz_r,
-                           d.rz_k, nrz, d.W, d.ldw, d.drow, d.ag, d.beta, d.eps);
+        hipLaunchKernelGGL((k_fast_select_prep<0>), dim3(R_ + 1), dim3(256), 0, st, SEL_ARGS(0));
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_fast_select_prep<1>), dim3(R_ + 1), dim3(256), 0, st, SEL_ARGS(0));
     else
-        hipLaunchKernelGGL((k_fast_select_prep<1>), dim3(R_ + 1), dim3(256), 0, st, d.ctl, d.m, d.A,
-                           d.lda, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.rz_r,
-                           d.rz_k, nrz, d.W, d.ldw, d.drow, d.ag, d.beta, d.eps);
+        hipLaunchKernelGGL((k_fast_select_prep<2>), dim3(R_ + 1), dim3(256), 0, st,
+                           SEL_ARGS(mode == 2 ? DZG_STEP_PRIMAL : DZG_STEP_DUAL));
+#undef SEL_ARGS
 }
 
-void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, hipStream_t st)
+void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_gemv, dim3(DZG_NB_GEMV), dim3(256), 0, st, d.ctl, need_kind, d.m,
-                       d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.basis, d.nonbasis, d.var_col,
-                       d.x, d.xbar, d.dx, d.rx_r, d.rx_k);
+                       d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.col0, xrecv, d.xstride,
+                       d.basis, d.nonbasis, d.var_col, d.x, d.xbar, d.dx, d.rx_r, d.rx_k);
 }
 
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
@@ -635,15 +826,16 @@ void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_pivot, dim3(1), dim3(1024), 0, st, d.ctl, d.m, d.q, d.x, d.xbar, d.z,
                        d.zbar, d.dx, d.dz, d.v, d.basis, d.nonbasis, d.var_col, d.binv, d.ldb,
-                       d.drow, d.dslot, d.U, d.ldw, d.W, d.ldw, d.plist, d.pslot, d.log_kind, d.log_enter,
+                       d.drow, d.dslot, d.U, d.ldw, d.W, d.ldw, d.plist, d.pslot, d.col0, d.col1, d.log_kind,
+                       d.log_enter,
                        d.log_leave, d.log_mu, d.log_cap);
 }
 
 void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
-                       d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.fpx_r, d.fpx_k, d.fpz_r,
-                       d.fpz_k);
+                       d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.nonbasis, d.var_col, d.col0, d.col1,
+                       d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k);
 }
 
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
@@ -654,4 +846,27 @@ void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_fast_flush_mfma, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
                        d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
     hipLaunchKernelGGL(k_fast_flush_done, dim3(1), dim3(1), 0, st, d.ctl);
+}
+
+void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st)
+{
+    const dim3 grid(1 + (d.m + 255) / 256);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_shard_propose<0>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
+                           d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.fpz_r,
+                           d.fpz_k, DZG_NB_UPD, xsend);
+    else
+        hipLaunchKernelGGL((k_shard_propose<1>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
+                           d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.rz_r, d.rz_k,
+                           nrz, xsend);
+}
+
+void dzg_launch_shard_decide(const DzgDev &d, int mode, const double *xrecv, hipStream_t st)
+{
+    if (mode == 0)
+        hipLaunchKernelGGL((k_shard_decide<0>), dim3(1), dim3(256), 0, st, d.ctl, d.m, d.world,
+                           xrecv, d.xstride, d.fpx_r, d.fpx_k, d.eps);
+    else
+        hipLaunchKernelGGL((k_shard_decide<1>), dim3(1), dim3(256), 0, st, d.ctl, d.m, d.world,
+                           xrecv, d.xstride, d.fpx_r, d.fpx_k, d.eps);
 }

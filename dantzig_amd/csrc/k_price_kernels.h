@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_price_seq2(
     const int *__restrict__ plist, const int *__restrict__ nonbasis,
     const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
-    int *__restrict__ rz_k)
+    int *__restrict__ rz_k, int col0 = 0)
 {
     constexpr int TR = 128, PAD = 2; // column stride 130 doubles: lane c starts 4c banks on
     __shared__ __attribute__((aligned(16))) double tile[4][CW][TR + PAD];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_price_seq2(
         // unconditionally so that the compiler can count outstanding loads exactly
         // (s_waitcnt vmcnt(N) with N > 0 keeps the second tile in flight); columns past nc and
         // unit columns re-read the wave's last valid column (served by L1/L2) and are ignored.
-        int lastcode = 0;
+        int lastcode = col0;
 #pragma unroll
         for (int l = 0; l < CW; ++l) {
             const int code_l = __builtin_amdgcn_readlane(mycode, l);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_price_seq2(
 #pragma unroll
         for (int l = 0; l < CW; ++l) {
             const int code_l = __builtin_amdgcn_readlane(mycode, l);
-            off[l] = (long long)(code_l >= 0 ? code_l : lastcode) * lda;
+            off[l] = (long long)((code_l >= 0 ? code_l : lastcode) - col0) * lda;
         }
         double2_t rg[DEPTH][CW], vg[DEPTH]; // DEPTH tiles in flight, statically indexed
         double dbg_sink = 0.0;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_price_wave2(
     const int *__restrict__ plist, const int *__restrict__ nonbasis,
     const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
-    int *__restrict__ rz_k)
+    int *__restrict__ rz_k, int col0 = 0)
 {
     if (ctl && ctl->status != DZG_RUNNING) return;
     const int lane = threadIdx.x & 63;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_price_wave2(
         const int pos = plist ? plist[idx] : idx;
         const int code = price_code(nonbasis, var_col, pos);
         if (code < 0) continue;
-        const double *col = A + (long long)code * lda; // rows m..lda-1 are zero
+        const double *col = A + (long long)(code - col0) * lda; // rows m..lda-1 are zero
         double acc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = 0.0;

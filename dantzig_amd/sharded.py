@@ -1,0 +1,152 @@
+"""Column-sharded solve over several GPUs, one process per GPU.
+
+The iteration loop is native (csrc/engine.hip, dzg_shard_run):
+
+    phase1 -> ncclAllGather -> phase2 -> ncclAllGather -> phase3        (one simplex iteration)
+
+on one HIP stream per rank, RCCL over xGMI between the GPUs of a node.  Every rank holds the
+replicated basis inverse and x-side vectors and runs the same O(m k) basis kernels on identical
+inputs; the matrix, z and the pricing pass are split by column ownership.  All ranks merge the
+same exchange records with the same deterministic rule (largest ratio, lowest global position:
+the reference's first-wins scan, src/simplex.rs:432-435,:456-459), so they take identical
+decisions without a broadcast.
+
+Python only bootstraps: torch.distributed (gloo, CPU) hands the 128-byte ncclUniqueId from
+rank 0 to the other ranks and provides the barriers around the timed region.  torch.cuda is
+not used: the process talks to the GPU through one HIP runtime only (the library's).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import time
+
+import numpy as np
+
+from . import _ffi, core
+
+
+def col_range(n_struct: int, rank: int, world: int) -> tuple[int, int]:
+    """Balanced contiguous column block of `rank`."""
+    base, rem = divmod(n_struct, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class ShardedSolver(core.Solver):
+    """One rank's share of a column-sharded solve."""
+
+    def __init__(self, lp: core.CoreLP, rank: int, world: int, stream: int = 0, **opts):
+        begin, end = col_range(lp.n_struct, rank, world)
+        self.rank, self.world = rank, world
+        self.col_begin, self.col_end = begin, end
+        super().__init__(lp, numerics=core.FAST, rank=rank, world=world, col_begin=begin,
+                         col_end=end, stream=stream or None, **opts)
+        self.record_doubles = int(_ffi.lib().dzg_shard_record_doubles(self._h))
+
+    @property
+    def stream(self) -> int:
+        return int(_ffi.lib().dzg_solver_stream(self._h) or 0)
+
+    def comm_init(self, unique_id: bytes) -> None:
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _ffi.check(_ffi.lib().dzg_shard_comm_init(self._h, buf), "dzg_shard_comm_init")
+
+    def run(self, max_new_iters: int = 0) -> str:
+        rc = _ffi.lib().dzg_shard_run(self._h, int(max_new_iters))
+        _ffi.check(rc, "dzg_shard_run")
+        return core.STATUS_NAMES[rc]
+
+    def poll(self) -> tuple[str, int]:
+        st, it = C.c_int32(0), C.c_int64(0)
+        _ffi.check(_ffi.lib().dzg_solver_poll(self._h, C.byref(st), C.byref(it)), "poll")
+        return core.STATUS_NAMES.get(st.value, str(st.value)), int(it.value)
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _ffi.check(_ffi.lib().dzg_comm_unique_id(buf), "dzg_comm_unique_id")
+    return buf.raw
+
+
+def make_lockstep(lp: core.CoreLP, world: int, **opts) -> list:
+    """All ranks of a sharded solve inside ONE process on ONE GPU, sharing one stream."""
+    first = ShardedSolver(lp, 0, world, **opts)
+    return [first] + [ShardedSolver(lp, r, world, stream=first.stream, **opts)
+                      for r in range(1, world)]
+
+
+def run_lockstep(solvers: list, max_new_iters: int = 0) -> str:
+    """Native lockstep loop (dzg_shard_run_lockstep): the exchange is a device copy.  This is
+    how the sharded device path is tested on a single-GPU box."""
+    arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+    rc = _ffi.lib().dzg_shard_run_lockstep(arr, len(solvers), int(max_new_iters))
+    _ffi.check(rc, "dzg_shard_run_lockstep")
+    return core.STATUS_NAMES[rc]
+
+
+# ------------------------------------------------------------------ bench.py, N > 1
+def bench_main(args, rank: int, world: int, local_rank: int) -> int:
+    import torch
+    import torch.distributed as dist
+
+    _ffi.require_gpu()
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # bootstrap + barriers only
+    a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[args.price]
+    solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price)
+    del a, lp
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
+    dist.broadcast(uid, src=0)
+    solver.comm_init(uid.numpy().tobytes())
+
+    status = "iter_limit"
+    if args.warmup > 0:
+        status = solver.run(args.warmup)
+    it0 = solver.poll()[1]          # poll synchronises the stream
+    dist.barrier()
+    t0 = time.perf_counter()
+    if status == "iter_limit":
+        status = solver.run(args.steps)
+    it1 = solver.poll()[1]
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    res = solver.result(log=False)
+    pb = torch.tensor([res.price_bytes], dtype=torch.float64)
+    dist.all_reduce(pb, op=dist.ReduceOp.SUM)
+    record_bytes = 8 * solver.record_doubles
+    solver.close()
+    if rank == 0:
+        dt = float(elapsed.item())
+        steps = it1 - it0
+        print(json.dumps({
+            "metric": "simplex_iterations_per_sec",
+            "value": steps / dt if dt > 0 else float("nan"),
+            "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": it0,
+            "ms_per_step": 1e3 * dt / max(steps, 1), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"dense random LP {args.rows}x{args.cols} fp64, generator G1 seed "
+                            f"{args.seed}, column-sharded over {world} GPUs",
+                "numerics": "fast", "price_kernel": args.price,
+                "status_after_timed_region": status, "requested_steps": args.steps,
+                "exchanges_per_iteration": 2, "record_bytes": record_bytes,
+                "collective": "ncclAllGather (RCCL) of one record per rank",
+            },
+            "roofline": None, "cpu_baseline": None,
+            "pricing_bytes_all_ranks": float(pb.item()),
+        }))
+    dist.destroy_process_group()
+    return 0
+
+
+def all_gather_records(send, recv) -> None:
+    """recv[r] <- rank r's record, for every rank, with torch.distributed (any backend).
+    For hosts that drive dzg_shard_phase1/2/3 themselves instead of dzg_shard_run."""
+    import torch.distributed as dist
+
+    dist.all_gather_into_tensor(recv, send)

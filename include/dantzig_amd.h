@@ -107,6 +107,9 @@ typedef struct {
      * [col_begin, col_end); 0,0 = all.  See dzg_shard_* below. */
     int64_t col_begin, col_end;
     int32_t rank, world;
+    void *stream;             /* hipStream_t to enqueue on; NULL = a private stream.  A host that
+                                 interleaves its own collectives passes the stream they are
+                                 ordered against (torch.cuda.current_stream().cuda_stream)     */
 } dzg_opts;
 
 typedef struct {
@@ -252,6 +255,43 @@ typedef struct {
     int64_t pos;        /* GLOBAL nonbasic position of the candidate, INT64_MAX if none   */
     double y, ybar, dy; /* z, zbar, dz of the candidate (for the step lengths s, sbar)    */
 } dzg_candidate;
+
+/* A sharded solver is created with opts.world > 1, opts.rank and this rank's column block
+ * [col_begin, col_end) (FAST numerics; `a` holds ALL structural columns, only the block is
+ * uploaded).  One iteration = three enqueue-only phases with one all-gather of one record per
+ * rank between them; record = dzg_shard_record_doubles() doubles:
+ *   [0] ratio  [1] global nonbasic position (-1 = none)  [2] z  [3] zbar  [4] dz
+ *   [5] column code  [6..7] reserved  [8 .. 8+m) the candidate's column of A
+ * phase1: proposes this rank's first-pivot candidate on the z side (src/simplex.rs:275);
+ * phase2: merges the proposals (largest ratio, lowest position), runs status() and the part
+ *         of the step that precedes the second exchange (primal: FTRAN, x ratio test, BTRAN,
+ *         pricing of the owned columns; dual: BTRAN, pricing) and proposes the z-side ratio
+ *         candidate (dual) or publishes z, zbar, dz of the entering position (primal);
+ * phase3: merges, finishes the step (dual: FTRAN), pivots and updates.
+ * `send`/`recv` are DEVICE pointers owned by the host (recv holds world records in rank order).
+ * The library never calls a collective itself. */
+int64_t dzg_shard_record_doubles(const dzg_solver *s);
+int dzg_shard_phase1(dzg_solver *s, double *send_dev);
+int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *send_dev);
+int dzg_shard_phase3(dzg_solver *s, const double *recv_dev);
+/* The whole sharded loop in native code.  dzg_shard_comm_init joins this rank to an RCCL
+ * communicator (librccl is loaded lazily with dlopen; `unique_id` is the 128-byte ncclUniqueId
+ * produced by dzg_comm_unique_id on rank 0 and distributed by the host, e.g. over gloo);
+ * dzg_shard_run then iterates phase1 -> ncclAllGather -> phase2 -> ncclAllGather -> phase3 on
+ * the solver's stream (xGMI between the GPUs of a node) and polls the status word every
+ * poll_interval iterations.  Returns the status like dzg_solver_run. */
+int dzg_comm_unique_id(void *unique_id_128);
+int dzg_shard_comm_init(dzg_solver *s, const void *unique_id_128);
+int dzg_shard_run(dzg_solver *s, int64_t max_new_iters);
+/* All ranks inside one process on one device (solvers[r] created with rank r and a common
+ * opts.stream = dzg_solver_stream(solvers[0])): the exchange is a device-to-device copy.
+ * This is how the sharded device path is exercised on a single-GPU box. */
+int dzg_shard_run_lockstep(dzg_solver **solvers, int32_t world, int64_t max_new_iters);
+void *dzg_solver_stream(dzg_solver *s);
+/* Synchronises the stream and reads the status word and the pivot count. */
+int dzg_solver_poll(dzg_solver *s, int32_t *status, int64_t *iterations);
+/* Sets the run budget like dzg_solver_run does, without running (sharded hosts drive the loop). */
+int dzg_solver_set_budget(dzg_solver *s, int64_t max_new_iters);
 
 /* Deterministic max-loc merge: largest ratio wins, lowest global position on ties --
  * the sequential first-wins rule of src/simplex.rs:432-435,456-459.  Returns the index

@@ -1,0 +1,156 @@
+"""Column sharding.
+
+CPU (gloo, world_size 2): the host-side exchange -- column partition, all-gather of the
+candidate records through torch.distributed, deterministic merge (dzg_merge_candidates) --
+checked against the oracle's global ratio test on the same data.
+GPU: the complete sharded device path with all ranks inside one process on one GPU
+(run_lockstep: the exchange is a device copy), checked against the oracle's pivot log."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+
+def test_col_range_partitions():
+    from dantzig_amd.sharded import col_range
+
+    for ns in (1, 7, 16, 1000, 16384):
+        for world in (1, 2, 3, 8):
+            edges = [col_range(ns, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == ns
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [e - b for b, e in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_candidates_rule():
+    from dantzig_amd import core
+
+    inf = float("inf")
+    assert core.merge_candidates([(1.0, 5, 0, 0, 0), (2.0, 9, 0, 0, 0)]) == 1
+    assert core.merge_candidates([(2.0, 9, 0, 0, 0), (2.0, 3, 0, 0, 0)]) == 1  # tie -> lowest pos
+    assert core.merge_candidates([(0.0, -1, 0, 0, 0), (inf, 4, 0, 0, 0), (inf, 2, 0, 0, 0)]) == 2
+    assert core.merge_candidates([(0.0, -1, 0, 0, 0)]) == -1
+    assert core.merge_candidates([(float("nan"), 1, 0, 0, 0), (-3.0, 2, 0, 0, 0)]) == 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, seed, m, ns, out):
+    import torch.distributed as dist
+
+    from dantzig_amd import core
+    from tests.shard_protocol import solve_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the generator is host code of the product library (no GPU needed)
+        a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+        status, log = solve_sharded(np.array(a), b, c, rank, world)
+        out.put((rank, status, log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed,m,ns", [(41, 12, 20), (42, 24, 48), (43, 32, 40)])
+def test_sharded_protocol_over_gloo(seed, m, ns):
+    """Two OS processes, one rank each, records over gloo: the sharded protocol reproduces the
+    single-process oracle's pivot log on every rank."""
+    import torch.multiprocessing as mp
+
+    from dantzig_amd import core
+
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, seed, m, ns, out))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, status, log in results:
+        assert status == want.status == "optimal"
+        assert log == [(k, e, l) for k, e, l, _ in want.pivots]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,seed,m,ns", [(2, 31, 48, 96), (3, 32, 64, 100), (4, 33, 128, 256),
+                                             (8, 34, 96, 200)])
+def test_sharded_lockstep_matches_oracle(world, seed, m, ns):
+    from dantzig_amd import core
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    solvers = make_lockstep(lp, world, poll_interval=16)
+    try:
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == want.status == "optimal"
+    log = [(k, e, l) for k, e, l, _ in want.pivots]
+    for res in results:
+        assert [(k, e, l) for k, e, l, _ in res.pivots] == log
+        assert res.basis.tolist() == want.basis.tolist()
+        assert abs(res.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+    # every rank carries the same replicated x; z is only kept for owned / slack positions
+    for res in results[1:]:
+        assert np.array_equal(res.x, results[0].x)
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_loop():
+    """The native RCCL loop with a communicator of one rank (all a 1-GPU box can host): loads
+    librccl, ncclCommInitRank, two ncclAllGather per iteration on the solver's stream."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import ShardedSolver, comm_unique_id
+
+    a, b, c = core.gen_dense_lp(seed=36, m=64, n_struct=128)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    with ShardedSolver(lp, 0, 1, poll_interval=16) as s:
+        s.comm_init(comm_unique_id())
+        status = s.run()
+        res = s.result()
+    assert status == want.status == "optimal"
+    assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+
+
+@pytest.mark.gpu
+def test_sharded_budget_and_resume():
+    from dantzig_amd import core
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+
+    a, b, c = core.gen_dense_lp(seed=35, m=64, n_struct=128)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    solvers = make_lockstep(lp, 2, poll_interval=8)
+    try:
+        status, rounds = "iter_limit", 0
+        while status == "iter_limit":
+            status = run_lockstep(solvers, max_new_iters=50)
+            rounds += 1
+            assert rounds < 1000
+        res = solvers[0].result()
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == "optimal" and rounds > 1
+    assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
