@@ -152,7 +152,10 @@ Rccl &rccl()
 {
     static Rccl r;
     if (r.handle || r.ok) return r;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // ROCm's own librccl first, by path: it binds to the same libamdhip64 as this library.  A
+    // bare soname could resolve to a copy bundled with a Python package (its own HIP runtime).
+    const char *names[] = {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1",
+                           "librccl.so"};
     for (const char *n : names) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
