@@ -184,10 +184,11 @@ def main() -> int:
             "requested_steps": args.steps,
             "lp_generation_s": round(t_gen, 3),
             "upload_s": round(t_up, 3),
+            "max_pivot_error": r1.max_pivot_error,
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_price_seq" if args.price in ("auto", "seq") else "k_price_wave",
+            "kernel": "k_price_seq2" if (args.price == "seq" or (args.price == "auto" and args.cols >= 12288)) else "k_price_wave2",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

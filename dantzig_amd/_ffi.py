@@ -66,7 +66,7 @@ class Result(C.Structure):
         ("basis", C.c_void_p), ("nonbasis", C.c_void_p), ("x", C.c_void_p), ("xbar", C.c_void_p),
         ("z", C.c_void_p), ("zbar", C.c_void_p), ("log", C.c_void_p), ("log_cap", C.c_int64),
         ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_int64 * K_COUNT),
-        ("price_bytes", C.c_double), ("solve_ms", C.c_double),
+        ("price_bytes", C.c_double), ("solve_ms", C.c_double), ("max_pivot_error", C.c_double),
     ]
 
 

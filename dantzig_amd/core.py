@@ -73,6 +73,7 @@ class CoreResult:
     kernel_launches: dict = field(default_factory=dict)
     price_bytes: float = 0.0
     solve_ms: float = 0.0
+    max_pivot_error: float = 0.0
 
 
 class Solver:
@@ -134,7 +135,8 @@ class Solver:
             xbar=xbar[:m].copy(), z=z[:q].copy(), zbar=zbar[:q].copy(), pivots=pivots,
             kernel_ms={k: r.kernel_ms[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
             kernel_launches={k: r.kernel_launches[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
-            price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms))
+            price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms),
+            max_pivot_error=float(r.max_pivot_error))
 
     def close(self) -> None:
         if self._h:

@@ -39,6 +39,7 @@ struct DzgCtl {
     double zr, zbar_r, dz_r;
     int use_record;      // 1: k_fast_pivot takes zr/zbar_r/dz_r instead of its local z arrays
     int pad2;
+    double max_pivot_err; // FAST health: max |dx_p + dz_r| / max(|dx_p|, |dz_r|) over all pivots
 };
 
 // Partial-reduction fan-in sizes of the FAST pipeline (fixed grids => fixed counts)

@@ -394,7 +394,13 @@ struct Prof {
 
 static int price_kernel_for(const dzg_solver *s)
 {
-    return s->opts.price_kernel == DZG_PRICE_AUTO ? DZG_PRICE_SEQ : s->opts.price_kernel;
+    // AUTO: the sequential-order kernel (bit-identical sums) while every wave of its grid gets
+    // >= 12 columns -- above that it streams at the HBM rate; its serial additions cost
+    // ~120 us per 8192 rows however few columns there are, so smaller column sets (small LPs,
+    // column shards) take the tree-order kernel.
+    if (s->opts.price_kernel != DZG_PRICE_AUTO) return s->opts.price_kernel;
+    const long long local_cols = (long long)s->d.col1 - s->d.col0;
+    return local_cols >= 12ll * 1024 ? DZG_PRICE_SEQ : DZG_PRICE_WAVE;
 }
 
 static void enqueue_fast_iteration(dzg_solver *s, int slot)
@@ -767,6 +773,7 @@ extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
     }
     res->price_bytes = s->h_ctl->price_bytes;
     res->solve_ms = s->solve_ms;
+    res->max_pivot_error = s->h_ctl->max_pivot_err;
     return 0;
 }
 

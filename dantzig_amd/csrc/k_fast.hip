@@ -347,6 +347,14 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
         const double tbar = dzg_safe_divide(xbar[p], dx[p], &ok);
         const double sbar = dzg_safe_divide(zbr, dzr, &ok);
         if (neta >= R_) ok = 0; // the host flushes every DZG_RMAX pivots; never reached
+        // the pivot element is known twice: dx_p = (B^-1 a_j)_p from FTRAN and -dz_r = v . a_j
+        // from BTRAN + pricing.  Their disagreement measures what the explicit inverse lost.
+        {
+            const double a1 = fabs(dx[p]), a2 = fabs(dzr);
+            const double den = a1 > a2 ? a1 : a2;
+            const double err = den > 0.0 ? fabs(dx[p] + dzr) / den : 0.0;
+            if (err > ctl->max_pivot_err) ctl->max_pivot_err = err;
+        }
         if (ok) {
             ctl->t = t;
             ctl->s = s;

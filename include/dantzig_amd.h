@@ -143,6 +143,8 @@ typedef struct {
     int64_t kernel_launches[DZG_K_COUNT];
     double price_bytes;      /* algorithmic bytes of the pricing kernel, summed */
     double solve_ms;         /* wall time inside dzg_solver_run, summed                  */
+    double max_pivot_error;  /* FAST health monitor: max relative |dx_p + dz_r| over all pivots
+                                (the pivot element computed by FTRAN vs by BTRAN + pricing)   */
 } dzg_result;
 
 typedef struct dzg_solver dzg_solver;
