@@ -228,3 +228,32 @@ def test_reference_solver_kats_through_level2(kats, name):
             assert res.objective == want.objective
             assert values[:V].tolist() == want.values.tolist()
             assert res.iterations == want.iterations
+
+
+# ------------------------------------------------------------------ independent optimum (HiGHS)
+def _highs_cases():
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "highs_objectives.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", _highs_cases(), ids=lambda c: f"{c['m']}x{c['n_struct']}")
+def test_fast_full_solve_objective_matches_highs(core, case):
+    """Whole FAST solves at sizes the CPU oracle cannot finish, against the optimal value an
+    independent solver found for the same seeded LP (tests/golden/make_highs_fixtures.py).
+    Tolerance 1e-9 relative (BASELINE.json north_star)."""
+    a, b, c = core.gen_dense_lp(seed=case["seed"], m=case["m"], n_struct=case["n_struct"])
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    got = core.solve(lp, numerics=core.FAST, log=False, poll_interval=64)
+    assert got.status == "optimal"
+    want = case["objective"]
+    assert abs(got.objective - want) <= 1e-9 * max(1.0, abs(want)), (got.objective, want)
+    assert got.max_pivot_error < 1e-6
+    # the final point is primal feasible: A x_B <= b up to rounding
+    xs = np.zeros(case["n_struct"])
+    pos = got.basis < case["n_struct"]
+    xs[got.basis[pos]] = got.x[pos]
+    assert (np.array(a) @ xs - b).max() <= 1e-7 and xs.min() >= -1e-9
