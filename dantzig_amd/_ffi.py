@@ -31,7 +31,7 @@ EXPORTS = [
     "dzg_kernel_second_pivot", "dzg_gen_dense_lp", "dzg_merge_candidates",
     "dzg_shard_record_doubles", "dzg_shard_phase1", "dzg_shard_phase2", "dzg_shard_phase3",
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
-    "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream",
+    "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
 ]
 
 
@@ -50,7 +50,7 @@ class Opts(C.Structure):
         ("auto_strict_rows", C.c_int32), ("max_iter", C.c_int64), ("epsilon", C.c_double),
         ("log_capacity", C.c_int64), ("poll_interval", C.c_int32), ("profile", C.c_int32),
         ("col_begin", C.c_int64), ("col_end", C.c_int64), ("rank", C.c_int32),
-        ("world", C.c_int32), ("stream", C.c_void_p),
+        ("world", C.c_int32), ("stream", C.c_void_p), ("refactor_interval", C.c_int64),
     ]
 
 
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
         _lib.dzg_shard_run_lockstep.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
         _lib.dzg_solver_stream.restype = C.c_void_p
         _lib.dzg_solver_stream.argtypes = [C.c_void_p]
+        _lib.dzg_solver_refactor.argtypes = [C.c_void_p]
     return _lib
 
 

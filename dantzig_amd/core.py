@@ -138,6 +138,10 @@ class Solver:
             price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms),
             max_pivot_error=float(r.max_pivot_error))
 
+    def refactor(self) -> None:
+        """FAST: rebuild the basis inverse from scratch now (blocked LU + MFMA GEMMs)."""
+        _ffi.check(_ffi.lib().dzg_solver_refactor(self._h), "dzg_solver_refactor")
+
     def close(self) -> None:
         if self._h:
             _ffi.lib().dzg_solver_destroy(self._h)

@@ -86,6 +86,13 @@ struct dzg_solver {
     double constant = 0.0;
     double solve_ms = 0.0;
     int since_flush = 0; // iterations enqueued since the eta file was last folded into Binv0
+    // refactorisation workspace (FAST, opts.refactor_interval != 0)
+    double *rfG = nullptr, *rfX = nullptr;
+    long long rf_ld = 0;
+    int *rf_piv = nullptr, *rf_spos = nullptr, *rf_scode = nullptr, *rf_lpos = nullptr,
+        *rf_lrow = nullptr, *rf_counts = nullptr;
+    long long since_refactor = 0;
+    int64_t refactors = 0;
     // column sharding
     void *comm = nullptr;                  // ncclComm_t
     double *xsend = nullptr, *xrecv1 = nullptr, *xrecv2 = nullptr;
@@ -354,6 +361,14 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));
         TRY(dev_alloc(s, &d.fpx_k, np)); TRY(dev_alloc(s, &d.fpz_k, np));
         TRY(dev_alloc(s, &d.rx_k, np)); TRY(dev_alloc(s, &d.rz_k, np));
+        if (o.refactor_interval != 0) {
+            s->rf_ld = ((long long)m + 15) / 16 * 16 + 16;
+            TRY(dev_alloc(s, &s->rfG, (size_t)(m ? m : 1) * (size_t)s->rf_ld));
+            TRY(dev_alloc(s, &s->rfX, (size_t)(m ? m : 1) * (size_t)s->rf_ld));
+            TRY(dev_alloc(s, &s->rf_piv, (size_t)m)); TRY(dev_alloc(s, &s->rf_spos, (size_t)m));
+            TRY(dev_alloc(s, &s->rf_scode, (size_t)m)); TRY(dev_alloc(s, &s->rf_lpos, (size_t)m));
+            TRY(dev_alloc(s, &s->rf_lrow, (size_t)m)); TRY(dev_alloc(s, &s->rf_counts, 4));
+        }
         dzg_launch_fast_init(d, s->st);
         dzg_launch_fast_update(d, 1, s->st); // first-pivot partials of the initial state
     } else {
@@ -462,14 +477,48 @@ static int read_ctl(dzg_solver *s)
     return 0;
 }
 
+// Rebuild Binv0 from scratch for the current basis (k_refactor.hip).  One host sync to learn
+// k; everything else is enqueued.
+static int refactor_now(dzg_solver *s)
+{
+    if (!s->rfG) return fail(DZG_E_ARG, "refactor workspace not reserved (opts.refactor_interval)");
+    const DzgDev &d = s->d;
+    dzg_launch_refactor_lists(d, s->rf_spos, s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_counts, s->st);
+    int counts[2] = {0, 0};
+    HIP_OK(hipMemcpyAsync(counts, s->rf_counts, sizeof(counts), hipMemcpyDeviceToHost, s->st));
+    TRY(read_ctl(s));
+    if (s->h_ctl->status != DZG_RUNNING && s->h_ctl->status != DZG_ITER_LIMIT) return 0;
+    if (counts[0] != s->h_ctl->ncompact)
+        return fail(DZG_E_DEVICE, "refactor: structural basics != dense columns");
+    dzg_launch_refactor(d, counts[0], counts[1], s->rfG, s->rfX, s->rf_ld, s->rf_piv, s->rf_spos,
+                        s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_counts + 2, s->st);
+    s->since_flush = 0;
+    s->since_refactor = 0;
+    s->refactors += 1;
+    return 0;
+}
+
+extern "C" int dzg_solver_refactor(dzg_solver *s)
+{
+    if (!s || s->numerics != DZG_NUMERICS_FAST) return fail(DZG_E_ARG, "refactor: FAST solver");
+    HIP_OK(hipSetDevice(s->opts.device));
+    TRY(refactor_now(s));
+    HIP_OK(hipStreamSynchronize(s->st));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 static int run_fast(dzg_solver *s)
 {
     const int poll = s->opts.poll_interval;
     for (;;) {
+        if (s->opts.refactor_interval > 0 && s->since_refactor >= s->opts.refactor_interval)
+            TRY(refactor_now(s));
         const long long before = s->h_ctl->iter;
         long long remaining = s->h_ctl->iter_stop - before;
         int batch = (int)(remaining < poll ? (remaining < 1 ? 1 : remaining) : poll);
         for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
+        s->since_refactor += batch;
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
         collect_profile(s, (int)(s->h_ctl->iter - before));

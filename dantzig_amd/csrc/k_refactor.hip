@@ -1,0 +1,356 @@
+// k_refactor.hip -- FAST numerics: rebuild the compact basis inverse from scratch on the device.
+//
+// The reference refactorises in every iteration (Matrix::factorize, src/linalg.rs:88-128, twice
+// per pivot).  FAST numerics updates an explicit inverse instead and only REFACTORS now and then
+// (opts.refactor_interval, or when the pivot-consistency monitor drifts), to shed the rounding the
+// updates have accumulated.  With B = [A_S | E] (k structural basics S, rows R whose slack is
+// nonbasic) only the k x k block G = A[R, S] needs factorising:
+//
+//   1. gather G (row a = dense row drow[a], column b = b-th structural basic position)
+//   2. blocked right-looking LU with partial pivoting, panel width NB = 64:
+//        panel (one workgroup: pivot search = first maximum of |.|, swap, scale, rank-1 inside
+//        the panel)  ->  row swaps outside the panel  ->  U12 = L11^-1 A12  ->
+//        trailing update A22 -= L21 * U12 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
+//   3. X = G^-1 by blocked forward / backward substitution on the identity, every off-diagonal
+//      block product again an MFMA GEMM
+//   4. Binv0[p_b, :] = X[b, :] for structural positions, Binv0[p', :] = -A[r', S] * X for the
+//      position of the basic slack of row r' (one more MFMA GEMM), eta file emptied.
+//
+// ~2.7 k^3 + 2 (m-k) k^2 flops, all but the panels in GEMM form.
+#include "common.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define NB 64
+
+// ---------------------------------------------------------------------------------
+// C[M x N] (+)= alpha * A[M x K] * B[K x N], all row-major.  One wave owns a 16 x 64 strip of C
+// (4 MFMA tiles) and walks K in steps of 4.  ZERO_C: C = -A*B (no read of C); otherwise
+// C -= A*B.  crow (optional) maps strip rows to rows of C (scatter).
+// Lane maps (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// C/D[row = (l>>4) + 4*reg][col = l&15].
+// ---------------------------------------------------------------------------------
+template <bool ZERO_C>
+__global__ __launch_bounds__(256) void k_ref_gemm(int M, int N, int K, const double *__restrict__ A,
+                                                  long long lda, const double *__restrict__ B,
+                                                  long long ldb, double *__restrict__ C,
+                                                  long long ldc, const int *__restrict__ crow)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64;
+    const int i0 = (blockIdx.y * 4 + wave) * 16;
+    if (c0 >= N || i0 >= M) return;
+    const int li = lane & 15, lk = lane >> 4;
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            double cv = 0.0;
+            if (!ZERO_C && row < M && col < N)
+                cv = C[(long long)(crow ? crow[row] : row) * ldc + col];
+            acc[j][g] = cv;
+        }
+    }
+    const int arow = i0 + li;
+    const double *ap = A + (long long)(arow < M ? arow : 0) * lda;
+    for (int t0 = 0; t0 < K; t0 += 4) {
+        const int t = t0 + lk;
+        const bool tin = t < K;
+        const double a = (arow < M && tin) ? -ap[t] : 0.0;
+        const double *bp = B + (long long)(tin ? t : 0) * ldb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c0 + 16 * j + li;
+            const double b = (tin && col < N) ? bp[col] : 0.0;
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            if (row < M && col < N) C[(long long)(crow ? crow[row] : row) * ldc + col] = acc[j][g];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// lists: structural basic positions in position order (k of them), basic-slack positions
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ref_lists(DzgCtl *ctl, int m,
+                                                    const int *__restrict__ basis,
+                                                    const int *__restrict__ var_col,
+                                                    int *__restrict__ spos, int *__restrict__ scode,
+                                                    int *__restrict__ lpos, int *__restrict__ lrow,
+                                                    int *__restrict__ counts)
+{
+    // one workgroup; thread t owns positions [t*chunk, (t+1)*chunk): count, scan, fill
+    __shared__ int s_cnt[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (m + 1023) / 1024;
+    const int lo = tid * chunk, hi = (lo + chunk) < m ? (lo + chunk) : m;
+    int ns = 0;
+    for (int p = lo; p < hi; ++p) ns += var_col[basis[p]] >= 0 ? 1 : 0;
+    s_cnt[tid] = ns;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const int c = s_cnt[t];
+            s_cnt[t] = run;
+            run += c;
+        }
+        counts[0] = run;
+        counts[1] = m - run;
+    }
+    __syncthreads();
+    int is = s_cnt[tid];      // structural basics before this chunk
+    int il = lo < m ? lo - is : 0; // basic slacks before this chunk
+    for (int p = lo; p < hi; ++p) {
+        const int code = var_col[basis[p]];
+        if (code >= 0) {
+            spos[is] = p;
+            scode[is] = code;
+            ++is;
+        } else {
+            lpos[il] = p;
+            lrow[il] = -1 - code;
+            ++il;
+        }
+    }
+    (void)ctl;
+}
+
+// G[a][b] = A[drow[a], column of the b-th structural basic]; X = I.  grid (ceil(k/256), k)
+__global__ __launch_bounds__(256) void k_ref_gather(int k, const double *__restrict__ A,
+                                                    long long lda, int col0,
+                                                    const int *__restrict__ drow,
+                                                    const int *__restrict__ scode,
+                                                    double *__restrict__ G, double *__restrict__ X,
+                                                    long long ldg)
+{
+    const int a = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= k) return;
+    G[(long long)a * ldg + b] = A[(long long)(scode[b] - col0) * lda + drow[a]];
+    X[(long long)a * ldg + b] = (a == b) ? 1.0 : 0.0;
+}
+
+// panel j0..j0+nbw: unblocked LU with partial pivoting inside the panel columns (one workgroup)
+__global__ __launch_bounds__(1024) void k_ref_panel(int k, int j0, int nbw, double *__restrict__ G,
+                                                    long long ldg, int *__restrict__ piv,
+                                                    int *__restrict__ singular)
+{
+    __shared__ int s_p;
+    __shared__ double s_pivrow[NB];
+    const int tid = threadIdx.x;
+    for (int jj = 0; jj < nbw; ++jj) {
+        const int col = j0 + jj;
+        DzgCand best;
+        best.r = 0.0;
+        best.k = -1;
+        for (int i = col + tid; i < k; i += blockDim.x) {
+            DzgCand c;
+            c.r = fabs(G[(long long)i * ldg + col]);
+            c.k = i;
+            if (c.r == c.r) best = dzg_better(best, c);
+        }
+        best = dzg_block_best(best);
+        if (tid == 0) {
+            s_p = best.k >= 0 ? best.k : col;
+            piv[col] = s_p;
+            if (!(best.r > 0.0)) *singular = 1;
+        }
+        __syncthreads();
+        const int p = s_p;
+        // swap rows col <-> p inside the panel, keep the pivot row in LDS
+        if (tid < nbw) {
+            double *rc = G + (long long)col * ldg + j0 + tid;
+            double *rp = G + (long long)p * ldg + j0 + tid;
+            const double a = *rc, b = *rp;
+            *rc = b;
+            *rp = a;
+            s_pivrow[tid] = b;
+        }
+        __syncthreads();
+        const double pv = s_pivrow[jj];
+        const double rpv = pv != 0.0 ? 1.0 / pv : 0.0;
+        for (int i = col + 1 + tid; i < k; i += blockDim.x) {
+            double *row = G + (long long)i * ldg + j0;
+            const double l = row[jj] * rpv;
+            row[jj] = l;
+            for (int c = jj + 1; c < nbw; ++c) row[c] = fma(-l, s_pivrow[c], row[c]);
+        }
+        __syncthreads();
+    }
+}
+
+// apply the panel's row swaps to every column outside the panel of G and to all columns of X.
+// one thread per column.
+__global__ __launch_bounds__(256) void k_ref_swap(int k, int j0, int nbw, double *__restrict__ G,
+                                                  double *__restrict__ X, long long ldg,
+                                                  const int *__restrict__ piv)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * k) return;
+    double *Mx = c < k ? G : X;
+    const int col = c < k ? c : c - k;
+    if (c < k && col >= j0 && col < j0 + nbw) return; // the panel swapped itself
+    for (int jj = 0; jj < nbw; ++jj) {
+        const int r = j0 + jj, p = piv[r];
+        if (p != r) {
+            const double a = Mx[(long long)r * ldg + col], b = Mx[(long long)p * ldg + col];
+            Mx[(long long)r * ldg + col] = b;
+            Mx[(long long)p * ldg + col] = a;
+        }
+    }
+}
+
+// T[j0..j0+nbw, cbeg..cend) <- L11^-1 T[...]  (unit lower L11 = G[j0.., j0..]); thread per column
+__global__ __launch_bounds__(256) void k_ref_trsm_l(int j0, int nbw, const double *__restrict__ G,
+                                                    long long ldg, double *__restrict__ T,
+                                                    long long ldt, int cbeg, int cend)
+{
+    __shared__ double s_l[NB][NB + 1];
+    for (int e = threadIdx.x; e < nbw * nbw; e += blockDim.x)
+        s_l[e / nbw][e % nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
+    __syncthreads();
+    const int c = cbeg + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cend) return;
+    double y[NB];
+#pragma unroll 8
+    for (int i = 0; i < nbw; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
+    for (int i = 1; i < nbw; ++i) {
+        double acc = y[i];
+        for (int j = 0; j < i; ++j) acc = fma(-s_l[i][j], y[j], acc);
+        y[i] = acc;
+    }
+    for (int i = 0; i < nbw; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
+}
+
+// X[j0..j0+nbw, :) <- U11^-1 X[...]  (upper U11 with diagonal); thread per column
+__global__ __launch_bounds__(256) void k_ref_trsm_u(int j0, int nbw, const double *__restrict__ G,
+                                                    long long ldg, double *__restrict__ X,
+                                                    long long ldx, int ncols)
+{
+    __shared__ double s_u[NB][NB + 1];
+    for (int e = threadIdx.x; e < nbw * nbw; e += blockDim.x)
+        s_u[e / nbw][e % nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    double y[NB];
+    for (int i = 0; i < nbw; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
+    for (int i = nbw - 1; i >= 0; --i) {
+        double acc = y[i];
+        for (int j = i + 1; j < nbw; ++j) acc = fma(-s_u[i][j], y[j], acc);
+        y[i] = acc / s_u[i][i];
+    }
+    for (int i = 0; i < nbw; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
+}
+
+// Binv0[spos[b]][a] = X[b][a]   grid (ceil(k/256), k)
+__global__ __launch_bounds__(256) void k_ref_scatter(int k, const double *__restrict__ X,
+                                                     long long ldx, const int *__restrict__ spos,
+                                                     double *__restrict__ binv, long long ldb)
+{
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= k) return;
+    binv[(long long)spos[b] * ldb + a] = X[(long long)b * ldx + a];
+}
+
+// As[i][b] = A[lrow[i], column of the b-th structural basic]   grid (ceil(k/256), nl)
+__global__ __launch_bounds__(256) void k_ref_gather_slack(int k, const double *__restrict__ A,
+                                                          long long lda, int col0,
+                                                          const int *__restrict__ lrow,
+                                                          const int *__restrict__ scode,
+                                                          double *__restrict__ As, long long ldas)
+{
+    const int i = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= k) return;
+    As[(long long)i * ldas + b] = A[(long long)(scode[b] - col0) * lda + lrow[i]];
+}
+
+__global__ void k_ref_done(DzgCtl *ctl, const int *__restrict__ singular)
+{
+    ctl->neta = 0;
+    if (*singular) ctl->status = DZG_SINGULAR;
+}
+
+// ---------------------------------------------------------------------------------
+// host sequence.  k and nl are read back by the caller (one sync per refactor).
+// ---------------------------------------------------------------------------------
+void dzg_launch_refactor_lists(const DzgDev &d, int *spos, int *scode, int *lpos, int *lrow,
+                               int *counts, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ref_lists, dim3(1), dim3(1024), 0, st, d.ctl, d.m, d.basis, d.var_col, spos,
+                       scode, lpos, lrow, counts);
+}
+
+static void gemm_sub(int M, int N, int K, const double *A, long long lda, const double *B,
+                     long long ldb, double *C, long long ldc, hipStream_t st)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    hipLaunchKernelGGL((k_ref_gemm<false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, M, N,
+                       K, A, lda, B, ldb, C, ldc, (const int *)nullptr);
+}
+
+void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, long long ldg,
+                         int *piv, int *spos, int *scode, int *lpos, int *lrow, int *singular,
+                         hipStream_t st)
+{
+    hipMemsetAsync(singular, 0, sizeof(int), st);
+    if (k > 0) {
+        hipLaunchKernelGGL(k_ref_gather, dim3((k + 255) / 256, k), dim3(256), 0, st, k, d.A, d.lda,
+                           d.col0, d.drow, scode, G, X, ldg);
+        // ---- LU of G with the forward substitution of X riding along
+        for (int j0 = 0; j0 < k; j0 += NB) {
+            const int nbw = (k - j0) < NB ? (k - j0) : NB;
+            const int rest = k - j0 - nbw;
+            hipLaunchKernelGGL(k_ref_panel, dim3(1), dim3(1024), 0, st, k, j0, nbw, G, ldg, piv,
+                               singular);
+            hipLaunchKernelGGL(k_ref_swap, dim3((2 * k + 255) / 256), dim3(256), 0, st, k, j0, nbw, G,
+                               X, ldg, piv);
+            if (rest > 0) // U12 = L11^-1 A12
+                hipLaunchKernelGGL(k_ref_trsm_l, dim3((rest + 255) / 256), dim3(256), 0, st, j0, nbw,
+                                   G, ldg, G, ldg, j0 + nbw, k);
+            // forward substitution block of X (all k columns)
+            hipLaunchKernelGGL(k_ref_trsm_l, dim3((k + 255) / 256), dim3(256), 0, st, j0, nbw, G, ldg,
+                               X, ldg, 0, k);
+            if (rest > 0) {
+                const double *L21 = G + (long long)(j0 + nbw) * ldg + j0;
+                // A22 -= L21 * U12
+                gemm_sub(rest, rest, nbw, L21, ldg, G + (long long)j0 * ldg + j0 + nbw, ldg,
+                         G + (long long)(j0 + nbw) * ldg + j0 + nbw, ldg, st);
+                // X2 -= L21 * X1
+                gemm_sub(rest, k, nbw, L21, ldg, X + (long long)j0 * ldg, ldg,
+                         X + (long long)(j0 + nbw) * ldg, ldg, st);
+            }
+        }
+        // ---- backward substitution with U
+        const int last = ((k - 1) / NB) * NB;
+        for (int j0 = last; j0 >= 0; j0 -= NB) {
+            const int nbw = (k - j0) < NB ? (k - j0) : NB;
+            hipLaunchKernelGGL(k_ref_trsm_u, dim3((k + 255) / 256), dim3(256), 0, st, j0, nbw, G, ldg, X,
+                               ldg, k);
+            if (j0 > 0) // X[0..j0) -= U01 * X1
+                gemm_sub(j0, k, nbw, G + j0, ldg, X + (long long)j0 * ldg, ldg, X, ldg, st);
+        }
+        // ---- Binv0 rows of the structural positions
+        hipLaunchKernelGGL(k_ref_scatter, dim3((k + 255) / 256, k), dim3(256), 0, st, k, X, ldg, spos,
+                           d.binv, d.ldb);
+        // ---- Binv0 rows of the basic slacks: -A[r', S] * X   (G is free now: reuse it for A[r', S])
+        if (nl > 0) {
+            hipLaunchKernelGGL(k_ref_gather_slack, dim3((k + 255) / 256, nl), dim3(256), 0, st, k, d.A,
+                               d.lda, d.col0, lrow, scode, G, ldg);
+            hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
+                               nl, k, k, G, ldg, X, ldg, d.binv, d.ldb, (const int *)lpos);
+        }
+    }
+    hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);
+}

@@ -110,6 +110,9 @@ typedef struct {
     void *stream;             /* hipStream_t to enqueue on; NULL = a private stream.  A host that
                                  interleaves its own collectives passes the stream they are
                                  ordered against (torch.cuda.current_stream().cuda_stream)     */
+    int64_t refactor_interval; /* FAST: rebuild the basis inverse from scratch (blocked LU with
+                                 partial pivoting, fp64-MFMA trailing updates) every this many
+                                 pivots; 0 = never (the eta file is still folded in every 64)  */
 } dzg_opts;
 
 typedef struct {
@@ -167,6 +170,9 @@ int dzg_solver_run(dzg_solver *s, int64_t max_new_iters);
 /* Copies state, pivot log and counters back to the host. */
 int dzg_solver_result(dzg_solver *s, dzg_result *res);
 void dzg_solver_destroy(dzg_solver *s);
+/* FAST: rebuild the basis inverse from scratch now (needs opts.refactor_interval != 0 at
+ * creation, which reserves the workspace). */
+int dzg_solver_refactor(dzg_solver *s);
 /* create + run + result + destroy */
 int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res);
 

@@ -257,3 +257,36 @@ def test_fast_full_solve_objective_matches_highs(core, case):
     pos = got.basis < case["n_struct"]
     xs[got.basis[pos]] = got.x[pos]
     assert (np.array(a) @ xs - b).max() <= 1e-7 and xs.min() >= -1e-9
+
+
+# ------------------------------------------------------------------ FAST refactorisation
+@pytest.mark.parametrize("seed,m,ns,interval", [(51, 64, 128, 40), (52, 128, 256, 96),
+                                                (53, 200, 300, 64), (54, 150, 450, 17)])
+def test_fast_refactor_keeps_pivot_sequence(core, seed, m, ns, interval):
+    """Rebuilding the basis inverse from scratch (blocked LU with partial pivoting, MFMA
+    trailing updates, explicit inverse) every few pivots must not change a single pivot."""
+    lp, want = _oracle_dense(core, seed, m, ns)
+    got = core.solve(lp, numerics=core.FAST, refactor_interval=interval, poll_interval=8)
+    assert got.status == want.status == "optimal"
+    assert _log(got) == _log(want)
+    assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+    assert got.max_pivot_error < 1e-9
+
+
+def test_fast_refactor_on_demand_large(core):
+    """Refactor in the middle of a larger solve (k in the hundreds, several LU panels) and
+    finish: the optimum must still match the independent HiGHS value."""
+    case = next(c for c in _highs_cases() if c["m"] == 1024)
+    a, b, c = core.gen_dense_lp(seed=case["seed"], m=case["m"], n_struct=case["n_struct"])
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    with core.Solver(lp, numerics=core.FAST, refactor_interval=-1, poll_interval=64) as s:
+        for _ in range(6):
+            if s.run(2500) != "iter_limit":
+                break
+            s.refactor()
+        while s.run(0) == "iter_limit":
+            pass
+        got = s.result(log=False)
+    assert got.status == "optimal"
+    assert abs(got.objective - case["objective"]) <= 1e-9 * max(1.0, abs(case["objective"]))
+    assert got.max_pivot_error < 1e-9
