@@ -113,6 +113,8 @@ def main() -> int:
     ap.add_argument("--numerics", choices=["fast", "strict"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc-traffic", action="store_true")
+    ap.add_argument("--sparse-per-col", type=int, default=0,
+                    help="generator G2: this many nonzeros per column, matrix kept CSC on the device")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the column-sharded RCCL path even with one rank (rehearsal)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
@@ -138,8 +140,12 @@ def main() -> int:
     # its stream, which brackets the timed region the way torch.cuda.synchronize() would.
     _ffi.require_gpu()
     t_gen = time.perf_counter()
-    a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
-    lp = core.CoreLP.from_inequality_form(a, b, c)
+    if args.sparse_per_col > 0:
+        cp, ri, val, b, c = core.gen_sparse_lp(args.seed, args.rows, args.cols, args.sparse_per_col)
+        lp = core.CoreLP.from_csc(args.rows, cp, ri, val, b, c)
+    else:
+        a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
+        lp = core.CoreLP.from_inequality_form(a, b, c)
     t_gen = time.perf_counter() - t_gen
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[args.price]
     numerics = core.FAST if args.numerics == "fast" else core.STRICT
@@ -177,7 +183,10 @@ def main() -> int:
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"dense random LP {args.rows}x{args.cols} fp64, generator G1 seed {args.seed}",
+            "workload": (f"dense random LP {args.rows}x{args.cols} fp64, generator G1 seed {args.seed}"
+                         if args.sparse_per_col <= 0 else
+                         f"sparse random LP {args.rows}x{args.cols} fp64, {args.sparse_per_col} "
+                         f"nonzeros per column (CSC), generator G2 seed {args.seed}"),
             "numerics": r1.numerics,
             "price_kernel": args.price,
             "status_after_timed_region": status,
@@ -188,7 +197,7 @@ def main() -> int:
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_price_seq2" if (args.price == "seq" or (args.price == "auto" and args.cols >= 12288)) else "k_price_wave2",
+            "kernel": ("k_price_csc" if args.sparse_per_col > 0 else "k_price_seq2" if (args.price == "seq" or (args.price == "auto" and args.cols >= 12288)) else "k_price_wave2"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -28,7 +28,7 @@ EXPORTS = [
     "dzg_opts_default", "dzg_solver_create", "dzg_solver_run", "dzg_solver_result",
     "dzg_solver_destroy", "dzg_core_solve", "dzg_model_solve", "dzg_build_standard_form",
     "dzg_kernel_lu_solve", "dzg_kernel_neg_t_dot", "dzg_kernel_first_pivot",
-    "dzg_kernel_second_pivot", "dzg_gen_dense_lp", "dzg_merge_candidates",
+    "dzg_kernel_second_pivot", "dzg_gen_dense_lp", "dzg_gen_sparse_lp", "dzg_merge_candidates",
     "dzg_shard_record_doubles", "dzg_shard_phase1", "dzg_shard_phase2", "dzg_shard_phase3",
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
@@ -41,6 +41,7 @@ class Lp(C.Structure):
         ("a", C.c_void_p), ("lda", C.c_int64), ("var_col", C.c_void_p),
         ("c", C.c_void_p), ("constant", C.c_double),
         ("basis", C.c_void_p), ("nonbasis", C.c_void_p), ("x", C.c_void_p), ("z", C.c_void_p),
+        ("col_ptr", C.c_void_p), ("row_idx", C.c_void_p), ("val", C.c_void_p),
     ]
 
 

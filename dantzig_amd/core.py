@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "optimal", 1: "unbounded", 2: "infeasible", 3: "iter_limit", 
 @dataclass
 class CoreLP:
     """maximise c.x + constant  s.t.  [A | slacks] x = rhs, x >= 0, in Simplex::new's layout."""
-    a: np.ndarray                 # (m, n_struct) any layout; uploaded column-major
+    a: np.ndarray | None          # (m, n_struct) any layout; uploaded column-major.  None: CSC
     c: np.ndarray                 # n
     basis: np.ndarray             # m
     nonbasis: np.ndarray          # n - m
@@ -30,14 +30,18 @@ class CoreLP:
     z: np.ndarray                 # n - m
     var_col: np.ndarray | None = None
     constant: float = 0.0
+    # sparse structural block (used when a is None): CSC, rows ascending inside a column
+    col_ptr: np.ndarray | None = None
+    row_idx: np.ndarray | None = None
+    val: np.ndarray | None = None
 
     @property
     def m(self) -> int:
-        return int(self.a.shape[0])
+        return int(self.a.shape[0]) if self.a is not None else len(self.basis)
 
     @property
     def n_struct(self) -> int:
-        return int(self.a.shape[1])
+        return int(self.a.shape[1]) if self.a is not None else len(self.col_ptr) - 1
 
     @property
     def n(self) -> int:
@@ -53,6 +57,16 @@ class CoreLP:
                    basis=np.arange(ns, ns + m, dtype=np.int64),
                    nonbasis=np.arange(ns, dtype=np.int64), x=f64(b).copy(), z=-f64(c),
                    var_col=None, constant=constant)
+
+    @classmethod
+    def from_csc(cls, m, col_ptr, row_idx, val, b, c, constant: float = 0.0) -> "CoreLP":
+        """Same convention with the structural block in CSC (kept sparse on the device)."""
+        ns = len(col_ptr) - 1
+        return cls(a=None, c=np.concatenate([f64(c), np.zeros(m)]),
+                   basis=np.arange(ns, ns + m, dtype=np.int64),
+                   nonbasis=np.arange(ns, dtype=np.int64), x=f64(b).copy(), z=-f64(c),
+                   constant=constant, col_ptr=i64(col_ptr),
+                   row_idx=np.ascontiguousarray(row_idx, dtype=np.int32), val=f64(val))
 
 
 @dataclass
@@ -84,17 +98,22 @@ class Solver:
         self._lp = lp
         m, ns, n = lp.m, lp.n_struct, lp.n
         # column-major m x ns == C-contiguous (ns, m)
-        a_cm = np.ascontiguousarray(np.asarray(lp.a, dtype=np.float64).T)
+        a_cm = None if lp.a is None else np.ascontiguousarray(np.asarray(lp.a, dtype=np.float64).T)
         self._keep = dict(a=a_cm, c=f64(lp.c), basis=i64(lp.basis), nonbasis=i64(lp.nonbasis),
                           x=f64(lp.x), z=f64(lp.z),
-                          var_col=None if lp.var_col is None else i64(lp.var_col))
+                          var_col=None if lp.var_col is None else i64(lp.var_col),
+                          col_ptr=None if lp.col_ptr is None else i64(lp.col_ptr),
+                          row_idx=None if lp.row_idx is None
+                          else np.ascontiguousarray(lp.row_idx, dtype=np.int32),
+                          val=None if lp.val is None else f64(lp.val))
         k = self._keep
         if len(k["basis"]) != m or len(k["x"]) != m or len(k["nonbasis"]) != n - m \
                 or len(k["z"]) != n - m:
             raise ValueError("CoreLP vectors do not match (m, n)")
         self._c_lp = _ffi.Lp(m, n, ns, ptr(a_cm), max(m, 1), ptr(k["var_col"]), ptr(k["c"]),
                              float(lp.constant), ptr(k["basis"]), ptr(k["nonbasis"]),
-                             ptr(k["x"]), ptr(k["z"]))
+                             ptr(k["x"]), ptr(k["z"]), ptr(k["col_ptr"]), ptr(k["row_idx"]),
+                             ptr(k["val"]))
         self._opts = _ffi.default_opts(**opts)
         self._h = C.c_void_p(None)
         rc = _ffi.lib().dzg_solver_create(C.byref(self._c_lp), C.byref(self._opts),
@@ -176,6 +195,19 @@ def gen_dense_lp(seed: int, m: int, n_struct: int):
     rc = _ffi.lib().dzg_gen_dense_lp(C.c_uint64(seed), m, n_struct, ptr(a), m, ptr(b), ptr(c))
     _ffi.check(rc, "dzg_gen_dense_lp")
     return a.T, b, c
+
+
+def gen_sparse_lp(seed: int, m: int, n_struct: int, per_col: int):
+    """Generator G2.  Returns (col_ptr, row_idx, val, b, c) with `per_col` nonzeros per column."""
+    col_ptr = np.zeros(n_struct + 1, dtype=np.int64)
+    row_idx = np.zeros(n_struct * per_col, dtype=np.int32)
+    val = np.zeros(n_struct * per_col)
+    b, c = np.empty(m), np.empty(n_struct)
+    rc = _ffi.lib().dzg_gen_sparse_lp(C.c_uint64(seed), C.c_int64(m), C.c_int64(n_struct),
+                                      C.c_int64(per_col), ptr(col_ptr), ptr(row_idx), ptr(val),
+                                      ptr(b), ptr(c))
+    _ffi.check(rc, "dzg_gen_sparse_lp")
+    return col_ptr, row_idx, val, b, c
 
 
 # ------------------------------------------------------------------ single reference functions

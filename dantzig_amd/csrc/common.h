@@ -39,6 +39,7 @@ struct DzgCtl {
     double zr, zbar_r, dz_r;
     int use_record;      // 1: k_fast_pivot takes zr/zbar_r/dz_r instead of its local z arrays
     int pad2;
+    long long nb_nnz;     // sparse mode: stored entries of the owned nonbasic structural columns
     double max_pivot_err; // FAST health: max |dx_p + dz_r| / max(|dx_p|, |dz_r|) over all pivots
 };
 
@@ -125,7 +126,12 @@ struct DzgDev {
     // problem
     int m, q, n, ns;
     long long lda;
-    const double *A;   // column-major m x ns, lda
+    const double *A;   // column-major m x ns, lda (dense mode)
+    // sparse mode (csc != 0): the owned structural columns in CSC, rows ascending per column
+    int csc;
+    const long long *cptr; // [col1 - col0 + 1]
+    const int *ridx;       // [nnz]
+    const double *cval;    // [nnz]
     const int *var_col; // n
     // state
     int *basis, *nonbasis; // m, q
@@ -190,6 +196,7 @@ int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st);
 int dzg_price_partials(int kernel);
+#define DZG_PRICE_CSC_KERNEL 100 // internal id: the CSC pricing kernel
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st);
 

@@ -124,7 +124,20 @@ static int validate(const dzg_lp *lp, std::string &why)
     if (!lp) { why = "lp is NULL"; return 0; }
     if (lp->m < 0 || lp->n < lp->m || lp->n_struct < 0 || lp->n_struct > lp->n) { why = "bad sizes"; return 0; }
     if (lp->n >= (1ll << 31) - 64 || lp->m >= (1ll << 31) - 64) { why = "index range"; return 0; }
-    if (lp->n_struct > 0 && (!lp->a || lp->lda < lp->m)) { why = "a / lda"; return 0; }
+    if (lp->n_struct > 0 && lp->a && lp->lda < lp->m) { why = "lda"; return 0; }
+    if (lp->n_struct > 0 && !lp->a) {
+        if (!lp->col_ptr || lp->col_ptr[0] != 0) { why = "neither a nor col_ptr"; return 0; }
+        for (int64_t j = 0; j < lp->n_struct; ++j) {
+            if (lp->col_ptr[j + 1] < lp->col_ptr[j]) { why = "col_ptr not monotone"; return 0; }
+            for (int64_t e = lp->col_ptr[j]; e < lp->col_ptr[j + 1]; ++e) {
+                if (!lp->row_idx || !lp->val || lp->row_idx[e] < 0 || lp->row_idx[e] >= lp->m ||
+                    (e > lp->col_ptr[j] && lp->row_idx[e] <= lp->row_idx[e - 1])) {
+                    why = "row_idx must ascend strictly inside a column";
+                    return 0;
+                }
+            }
+        }
+    }
     const int64_t q = lp->n - lp->m;
     if ((lp->m > 0 && (!lp->basis || !lp->x)) || (q > 0 && (!lp->nonbasis || !lp->z)) || (lp->n > 0 && !lp->c)) { why = "NULL state vector"; return 0; }
     if (!lp->var_col && lp->n != lp->n_struct + lp->m) { why = "var_col == NULL needs n == n_struct + m"; return 0; }
@@ -180,6 +193,7 @@ const int kNcclFloat64 = 8;
 } // namespace
 
 static void shard_comm_destroy(dzg_solver *s);
+static int shard_buffers(dzg_solver *s);
 
 extern "C" void dzg_solver_destroy(dzg_solver *s)
 {
@@ -243,11 +257,37 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     const int nloc = d.col1 - d.col0; // structural columns resident on this device
     const double *a_host = lp->a ? lp->a + (size_t)d.col0 * (size_t)lp->lda : nullptr;
 
+    d.csc = (ns > 0 && !lp->a) ? 1 : 0;
+    if (d.csc) {
+        // sparse mode: the owned columns stay CSC on the device (12 bytes per nonzero); explicit
+        // zeros are dropped like the reference's From<&Matrix> for CscMatrix (src/linalg.rs:261)
+        std::vector<long long> cp((size_t)nloc + 1, 0);
+        std::vector<int> ri;
+        std::vector<double> cv;
+        for (int j = 0; j < nloc; ++j) {
+            for (int64_t e = lp->col_ptr[d.col0 + j]; e < lp->col_ptr[d.col0 + j + 1]; ++e)
+                if (lp->val[e] != 0.0) {
+                    ri.push_back((int)lp->row_idx[e]);
+                    cv.push_back(lp->val[e]);
+                }
+            cp[(size_t)j + 1] = (long long)ri.size();
+        }
+        long long *dcp; int *dri; double *dcv;
+        TRY(dev_alloc(s, &dcp, cp.size())); TRY(dev_alloc(s, &dri, ri.size() + 1));
+        TRY(dev_alloc(s, &dcv, cv.size() + 1));
+        HIP_OK(hipMemcpy(dcp, cp.data(), sizeof(long long) * cp.size(), hipMemcpyHostToDevice));
+        if (!ri.empty()) {
+            HIP_OK(hipMemcpy(dri, ri.data(), sizeof(int) * ri.size(), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(dcv, cv.data(), sizeof(double) * cv.size(), hipMemcpyHostToDevice));
+        }
+        d.cptr = dcp; d.ridx = dri; d.cval = dcv;
+    }
     // --- constraint matrix: column-major, zero-padded to lda rows (16-B aligned columns)
     double *A = nullptr;
-    TRY(dev_alloc(s, &A, (size_t)d.lda * (size_t)(nloc ? nloc : 1)));
-    HIP_OK(hipMemsetAsync(A, 0, sizeof(double) * (size_t)d.lda * (size_t)(nloc ? nloc : 1), s->st));
-    if (nloc > 0 && m > 0) {
+    const int ndense = d.csc ? 0 : nloc;
+    TRY(dev_alloc(s, &A, (size_t)d.lda * (size_t)(ndense ? ndense : 1)));
+    HIP_OK(hipMemsetAsync(A, 0, sizeof(double) * (size_t)d.lda * (size_t)(ndense ? ndense : 1), s->st));
+    if (ndense > 0 && m > 0) {
         // the reference's CSC drops exact zeros (src/linalg.rs:261), so -0.0 entries act as +0.0
         bool has_negzero = false;
         for (int64_t j = 0; j < nloc && !has_negzero; ++j)
@@ -361,6 +401,8 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));
         TRY(dev_alloc(s, &d.fpx_k, np)); TRY(dev_alloc(s, &d.fpz_k, np));
         TRY(dev_alloc(s, &d.rx_k, np)); TRY(dev_alloc(s, &d.rz_k, np));
+        if (o.refactor_interval != 0 && d.csc)
+            return fail(DZG_E_ARG, "refactorisation is not available for sparse (CSC) input yet");
         if (o.refactor_interval != 0) {
             s->rf_ld = ((long long)m + 15) / 16 * 16 + 16;
             TRY(dev_alloc(s, &s->rfG, (size_t)(m ? m : 1) * (size_t)s->rf_ld));
@@ -413,6 +455,7 @@ static int price_kernel_for(const dzg_solver *s)
     // >= 12 columns -- above that it streams at the HBM rate; its serial additions cost
     // ~120 us per 8192 rows however few columns there are, so smaller column sets (small LPs,
     // column shards) take the tree-order kernel.
+    if (s->d.csc) return DZG_PRICE_CSC_KERNEL;
     if (s->opts.price_kernel != DZG_PRICE_AUTO) return s->opts.price_kernel;
     const long long local_cols = (long long)s->d.col1 - s->d.col0;
     return local_cols >= 12ll * 1024 ? DZG_PRICE_SEQ : DZG_PRICE_WAVE;
@@ -517,7 +560,19 @@ static int run_fast(dzg_solver *s)
         const long long before = s->h_ctl->iter;
         long long remaining = s->h_ctl->iter_stop - before;
         int batch = (int)(remaining < poll ? (remaining < 1 ? 1 : remaining) : poll);
-        for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
+        if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
+            TRY(shard_buffers(s));
+            const size_t nb = sizeof(double) * (size_t)s->d.xstride;
+            for (int b = 0; b < batch; ++b) {
+                TRY(dzg_shard_phase1(s, s->xsend));
+                HIP_OK(hipMemcpyAsync(s->xrecv1, s->xsend, nb, hipMemcpyDeviceToDevice, s->st));
+                TRY(dzg_shard_phase2(s, s->xrecv1, s->xsend));
+                HIP_OK(hipMemcpyAsync(s->xrecv2, s->xsend, nb, hipMemcpyDeviceToDevice, s->st));
+                TRY(dzg_shard_phase3(s, s->xrecv2));
+            }
+        } else {
+            for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
+        }
         s->since_refactor += batch;
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());

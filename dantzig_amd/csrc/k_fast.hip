@@ -328,7 +328,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const double *__restrict__ dz, const double *__restrict__ v, int *basis, int *nonbasis,
     const int *__restrict__ var_col, double *binv, long long ldb, int *drow, int *dslot,
     double *U, long long ldu, double *W, long long ldw, int *plist, int *pslot, int col0, int col1,
-    int *log_kind, int *log_enter,
+    const long long *__restrict__ cptr, int *log_kind, int *log_enter,
     int *log_leave, double *log_mu, long long log_cap)
 {
     __shared__ int s_ok, s_k, s_ce, s_last;
@@ -425,11 +425,21 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
         log_mu[it] = ctl->mu;
     }
     long long s = ctl->nb_struct;
-    ctl->price_bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
+    // algorithmic bytes of this iteration's pricing pass; sparse: 12 B per stored
+    // entry of the nonbasic structural columns + their column pointers
+    if (cptr)
+        ctl->price_bytes += 12.0 * (double)ctl->nb_nnz + 4.0 * (double)(s + 1) + 8.0 * (double)m +
+                            32.0 * (double)q;
+    else
+        ctl->price_bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
     basis[p] = vj;
     nonbasis[r] = vi;
     // nonbasic position r now holds vi instead of vj; the list only tracks OWNED columns
     const bool own_j = cj >= col0 && cj < col1, own_i = ci >= col0 && ci < col1;
+    if (cptr) {
+        if (own_j) ctl->nb_nnz -= cptr[cj - col0 + 1] - cptr[cj - col0];
+        if (own_i) ctl->nb_nnz += cptr[ci - col0 + 1] - cptr[ci - col0];
+    }
     if (own_j && !own_i) { // an owned structural column left the nonbasic set
         const int idx = pslot[r], lastpos = plist[s - 1];
         plist[idx] = lastpos;
@@ -593,7 +603,8 @@ __global__ void k_fast_flush_done(DzgCtl *ctl)
 __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, int *dslot,
                                                    const int *__restrict__ nonbasis,
                                                    const int *__restrict__ var_col, int *plist,
-                                                   int *pslot, int col0, int col1)
+                                                   int *pslot, int col0, int col1,
+                                                   const long long *__restrict__ cptr)
 {
     // single workgroup: the structural-position list must be built in position order
     for (int r = threadIdx.x; r < m; r += blockDim.x) dslot[r] = -1;
@@ -611,6 +622,13 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
             }
         }
         s_count = s;
+        long long nnz = 0;
+        if (cptr)
+            for (int i = 0; i < s; ++i) {
+                const int code = var_col[nonbasis[plist[i]]];
+                nnz += cptr[code - col0 + 1] - cptr[code - col0];
+            }
+        ctl->nb_nnz = nnz;
         ctl->ncompact = 0;
         ctl->neta = 0;
         ctl->nb_struct = s;
@@ -653,7 +671,8 @@ __global__ __launch_bounds__(256) void k_shard_propose(
     const DzgCtl *ctl, int m, const double *__restrict__ A, long long lda, int col0, int col1,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dz,
-    const double *__restrict__ pr, const int *__restrict__ pk, int np, double *__restrict__ rec)
+    const double *__restrict__ pr, const int *__restrict__ pk, int np, double *__restrict__ rec,
+    int csc)
 {
     if (ctl->status != DZG_RUNNING) return;
     double ratio = 0.0;
@@ -686,7 +705,26 @@ __global__ __launch_bounds__(256) void k_shard_propose(
     }
     if (!want_column || code < 0) return;
     const int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
-    if (i < m) rec[8 + i] = A[(long long)(code - col0) * lda + i];
+    // sparse matrix: zero the slot here, k_shard_scatter_col then drops the stored entries in
+    if (i < m) rec[8 + i] = csc ? 0.0 : A[(long long)(code - col0) * lda + i];
+}
+
+// CSC: scatter the proposed column's stored entries into the (zeroed) record.  One workgroup.
+__global__ __launch_bounds__(256) void k_shard_scatter_col(const DzgCtl *ctl, int mode,
+                                                           const long long *__restrict__ cptr,
+                                                           const int *__restrict__ ridx,
+                                                           const double *__restrict__ cval, int col0,
+                                                           int col1, double *__restrict__ rec)
+{
+    if (ctl->status != DZG_RUNNING) return;
+    if (mode == 1 && ctl->kind == DZG_STEP_PRIMAL) return; // no column in that record
+    const int pos = (int)rec[1], code = (int)rec[5];
+    if (pos < 0 || code < col0 || code >= col1) return;
+    const long long e0 = cptr[code - col0], e1 = cptr[code - col0 + 1];
+    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const double val = cval[e];
+        rec[8 + ridx[e]] = val;
+    }
 }
 
 // MODE 0: merge the proposals, then status() exactly as k_fast_select_prep<0>.
@@ -797,7 +835,7 @@ void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
     hipMemsetAsync(d.Wc, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
     hipLaunchKernelGGL(k_fast_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.dslot, d.nonbasis,
-                       d.var_col, d.plist, d.pslot, d.col0, d.col1);
+                       d.var_col, d.plist, d.pslot, d.col0, d.col1, d.csc ? d.cptr : nullptr);
 }
 
 void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,
@@ -834,7 +872,8 @@ void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_pivot, dim3(1), dim3(1024), 0, st, d.ctl, d.m, d.q, d.x, d.xbar, d.z,
                        d.zbar, d.dx, d.dz, d.v, d.basis, d.nonbasis, d.var_col, d.binv, d.ldb,
-                       d.drow, d.dslot, d.U, d.ldw, d.W, d.ldw, d.plist, d.pslot, d.col0, d.col1, d.log_kind,
+                       d.drow, d.dslot, d.U, d.ldw, d.W, d.ldw, d.plist, d.pslot, d.col0, d.col1,
+                       d.csc ? d.cptr : nullptr, d.log_kind,
                        d.log_enter,
                        d.log_leave, d.log_mu, d.log_cap);
 }
@@ -862,11 +901,14 @@ void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend,
     if (mode == 0)
         hipLaunchKernelGGL((k_shard_propose<0>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
                            d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.fpz_r,
-                           d.fpz_k, DZG_NB_UPD, xsend);
+                           d.fpz_k, DZG_NB_UPD, xsend, d.csc);
     else
         hipLaunchKernelGGL((k_shard_propose<1>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
                            d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.rz_r, d.rz_k,
-                           nrz, xsend);
+                           nrz, xsend, d.csc);
+    if (d.csc)
+        hipLaunchKernelGGL(k_shard_scatter_col, dim3(1), dim3(256), 0, st, d.ctl, mode, d.cptr,
+                           d.ridx, d.cval, d.col0, d.col1, xsend);
 }
 
 void dzg_launch_shard_decide(const DzgDev &d, int mode, const double *xrecv, hipStream_t st)

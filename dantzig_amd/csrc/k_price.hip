@@ -20,12 +20,26 @@ static void launch(int kernel, const DzgCtl *ctl, const double *A, long long lda
 // number of per-workgroup ratio partials the chosen kernel leaves in rz_r / rz_k
 int dzg_price_partials(int kernel)
 {
+    if (kernel == DZG_PRICE_CSC_KERNEL) return DZG_PRICE_CSC_BLOCKS;
     return resolve(kernel) == DZG_PRICE_WAVE ? DZG_PRICE_WAVE_BLOCKS : DZG_PRICE_SEQ_BLOCKS;
+}
+
+static void launch_csc(const DzgDev &d, const int *plist, const double *z, const double *zbar,
+                       double *rz_r, int *rz_k, hipStream_t st)
+{
+    if (d.q <= 0) return;
+    hipLaunchKernelGGL(k_price_csc, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl, d.cptr,
+                       d.ridx, d.cval, d.q, plist, d.nonbasis, d.var_col, d.v, d.dz, z, zbar, rz_r,
+                       rz_k, d.col0);
 }
 
 // STRICT numerics: every nonbasic position, no fused ratio test
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
 {
+    if (d.csc) {
+        launch_csc(d, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+        return;
+    }
     launch(kernel, d.ctl, d.A, d.lda, d.m, d.q, nullptr, d.nonbasis, d.var_col, d.v, d.dz, nullptr,
            nullptr, nullptr, nullptr, 0, st);
 }
@@ -33,6 +47,10 @@ void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
 // FAST numerics: structural positions from plist, ratio-test partials for the dual step
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
 {
+    if (d.csc) {
+        launch_csc(d, d.plist, d.z, d.zbar, d.rz_r, d.rz_k, st);
+        return;
+    }
     launch(kernel, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nonbasis, d.var_col, d.v, d.dz, d.z,
            d.zbar, d.rz_r, d.rz_k, d.col0, st);
 }

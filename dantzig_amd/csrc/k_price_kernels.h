@@ -337,5 +337,43 @@ __global__ __launch_bounds__(256) void k_price_wave2(
     price_publish(best, rz_r, rz_k);
 }
 
+// ---------------------------------------------------------------------------------
+// k_price_csc: sparse columns (CSC, rows ascending).  One thread per column walks its stored
+// entries in order: acc = acc + val * (-v[row]) -- literally the reference's neg_t_dot
+// (src/linalg.rs:199-207), so dz is bit-identical.  ~50 entries per column at config 4: the
+// whole pass moves 12 bytes per nonzero and is far from any roofline; the gathers of v hit L2.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_price_csc(
+    const DzgCtl *ctl, const long long *__restrict__ cptr, const int *__restrict__ ridx,
+    const double *__restrict__ cval, int q, const int *__restrict__ plist,
+    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const double *__restrict__ v, double *__restrict__ dz, const double *__restrict__ z,
+    const double *__restrict__ zbar, double *__restrict__ rz_r, int *__restrict__ rz_k, int col0)
+{
+    if (ctl && ctl->status != DZG_RUNNING) return;
+    const double mu = ctl ? ctl->mu : 0.0;
+    DzgCand best;
+    best.r = 0.0;
+    best.k = -1;
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, z, zbar);
+    const int count = plist ? (int)ctl->nb_struct : q;
+    const int nthreads = gridDim.x * blockDim.x;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += nthreads) {
+        const int pos = plist ? plist[idx] : idx;
+        const int code = price_code(nonbasis, var_col, pos);
+        if (code < 0) continue;
+        double acc = 0.0; // Iterator::sum identity
+        const long long e1 = cptr[code - col0 + 1];
+        for (long long e = cptr[code - col0]; e < e1; ++e) {
+            const double p = cval[e] * -v[ridx[e]];
+            acc = acc + p;
+        }
+        dz[pos] = acc;
+        if (z) price_candidate(best, acc, pos, mu, z, zbar);
+    }
+    price_publish(best, rz_r, rz_k);
+}
+
+#define DZG_PRICE_CSC_BLOCKS 512
 #define DZG_PRICE_SEQ_BLOCKS 256   // x 4 waves: one workgroup per CU
 #define DZG_PRICE_WAVE_BLOCKS 2048 // x 4 waves

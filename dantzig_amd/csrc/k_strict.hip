@@ -24,11 +24,31 @@ __global__ __launch_bounds__(256) void k_gather_basis(const DzgCtl *ctl, double 
                                                       int m, const double *__restrict__ A,
                                                       long long lda, const int *__restrict__ basis,
                                                       const int *__restrict__ var_col,
-                                                      int transposed)
+                                                      int transposed,
+                                                      const long long *__restrict__ cptr,
+                                                      const int *__restrict__ ridx,
+                                                      const double *__restrict__ cval)
 {
     if (ctl->status != DZG_RUNNING) return;
     const int b = blockIdx.x; // basis position
     const int code = var_col[basis[b]];
+    if (cptr && code >= 0) { // sparse column: zero this workgroup's row/column of W, then scatter
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            if (transposed)
+                W[(long long)b * m + i] = 0.0;
+            else
+                W[(long long)i * m + b] = 0.0;
+        }
+        __syncthreads();
+        for (long long e = cptr[code] + threadIdx.x; e < cptr[code + 1]; e += blockDim.x) {
+            const int i = ridx[e];
+            if (transposed)
+                W[(long long)b * m + i] = cval[e];
+            else
+                W[(long long)i * m + b] = cval[e];
+        }
+        return;
+    }
     const double *col = code >= 0 ? A + (long long)code * lda : nullptr;
     const int srow = -1 - code;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
@@ -187,7 +207,7 @@ static void factorize_and_solve(int n, double *W, double *Lt, int *piv, double *
 void dzg_launch_strict_solve(const DzgDev &d, int transposed, hipStream_t st)
 {
     hipLaunchKernelGGL(k_gather_basis, dim3(d.m), dim3(256), 0, st, d.ctl, d.lu, d.m, d.A, d.lda,
-                       d.basis, d.var_col, transposed);
+                       d.basis, d.var_col, transposed, d.csc ? d.cptr : nullptr, d.ridx, d.cval);
     factorize_and_solve(d.m, d.lu, d.lt, d.piv, d.urow, d.krow, d.lcol, d.ctl,
                         transposed ? d.v : d.dx, st);
 }

@@ -188,11 +188,19 @@ __global__ __launch_bounds__(256) void k_update_vectors(const DzgCtl *ctl, doubl
 __global__ __launch_bounds__(256) void k_load_column(const DzgCtl *ctl, int need_kind,
                                                      const double *A, long long lda,
                                                      const int *nonbasis, const int *var_col,
-                                                     double *acol, int m)
+                                                     double *acol, int m, const long long *cptr,
+                                                     const int *ridx, const double *cval)
 {
     if (ctl->status != DZG_RUNNING) return;
     if (need_kind >= 0 && ctl->kind != need_kind) return;
     const int col = var_col[nonbasis[ctl->enter_pos]];
+    if (cptr && col >= 0) { // sparse column (single workgroup): zero, then scatter
+        for (int i = threadIdx.x; i < m; i += blockDim.x) acol[i] = 0.0;
+        __syncthreads();
+        for (long long e = cptr[col] + threadIdx.x; e < cptr[col + 1]; e += blockDim.x)
+            acol[ridx[e]] = cval[e];
+        return;
+    }
     const int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
         acol[i] = col >= 0 ? A[(long long)col * lda + i] : ((-1 - col) == i ? 1.0 : 0.0);
@@ -247,8 +255,9 @@ void dzg_launch_update_vectors(const DzgDev &d, hipStream_t st)
 
 void dzg_launch_load_column(const DzgDev &d, int need_kind, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_load_column, dim3(grid_for(d.m, 256, 256)), dim3(256), 0, st, d.ctl,
-                       need_kind, d.A, d.lda, d.nonbasis, d.var_col, d.acol, d.m);
+    hipLaunchKernelGGL(k_load_column, dim3(d.csc ? 1 : grid_for(d.m, 256, 256)), dim3(256), 0, st,
+                       d.ctl, need_kind, d.A, d.lda, d.nonbasis, d.var_col, d.acol, d.m,
+                       d.csc ? d.cptr : nullptr, d.ridx, d.cval);
 }
 
 void dzg_launch_unit_rhs(const DzgDev &d, hipStream_t st)

@@ -91,6 +91,12 @@ typedef struct {
     const int64_t *nonbasis; /* n-m initial nonbasic variable per position (Simplex.n)  */
     const double *x;         /* m   initial x (= rhs)                                   */
     const double *z;         /* n-m initial z (= -c of the nonbasic variables)          */
+    /* Sparse alternative to `a` (used when a == NULL): the structural block in CSC, exactly
+     * the reference's CscMatrix (src/linalg.rs:161-168): rows ascending inside a column, no
+     * explicit zeros.  Kept as CSC on the device (12 bytes per nonzero). */
+    const int64_t *col_ptr;  /* n_struct + 1                                            */
+    const int32_t *row_idx;  /* nnz                                                     */
+    const double *val;       /* nnz                                                     */
 } dzg_lp;
 
 typedef struct {
@@ -248,6 +254,12 @@ int dzg_kernel_second_pivot(int64_t len, double mu, const double *y, const doubl
                             const double *dy, int64_t *pos_out, int32_t device);
 
 /* ---- synthetic LPs of SURVEY 8(d) (host code, SplitMix64; used by bench and tests) -- */
+
+/* Generator G2 (sparse): `per_col` nonzeros per column at distinct rows (sorted ascending),
+ * values 2u-1 (redrawn if 0), b = A x0 + rb, c = A^T y0 - rc as in G1.
+ * col_ptr[n_struct+1], row_idx[n_struct*per_col], val[n_struct*per_col], b[m], c[n_struct]. */
+int dzg_gen_sparse_lp(uint64_t seed, int64_t m, int64_t n_struct, int64_t per_col,
+                      int64_t *col_ptr, int32_t *row_idx, double *val, double *b, double *c);
 
 /* Generator G1: dense m x n_struct LP, primal- and dual-feasible by construction.
  * a[lda*n_struct] column-major, b[m], c[n_struct]. */

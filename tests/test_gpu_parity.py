@@ -290,3 +290,39 @@ def test_fast_refactor_on_demand_large(core):
     assert got.status == "optimal"
     assert abs(got.objective - case["objective"]) <= 1e-9 * max(1.0, abs(case["objective"]))
     assert got.max_pivot_error < 1e-9
+
+
+# ------------------------------------------------------------------ sparse (CSC) input
+def _oracle_sparse(core, seed, m, ns, per_col):
+    cp, ri, val, b, c = core.gen_sparse_lp(seed, m, ns, per_col)
+    # oracle: full CSC over all n columns (structural block + identity slacks)
+    col_ptr = np.concatenate([cp, cp[-1] + 1 + np.arange(m)])
+    row_idx = np.concatenate([ri.astype(np.int64), np.arange(m)])
+    vals = np.concatenate([val, np.ones(m)])
+    sf = ora.StdForm(m=m, n=ns + m, col_ptr=col_ptr, row_idx=row_idx, val=vals,
+                     c=np.concatenate([c, np.zeros(m)]), constant=0.0,
+                     basis=np.arange(ns, ns + m), nonbasis=np.arange(ns), x=b.copy(), z=-c)
+    want = ora.simplex_solve(sf)
+    return core.CoreLP.from_csc(m, cp, ri, val, b, c), want
+
+
+@pytest.mark.parametrize("seed,m,ns,per_col", [(61, 24, 60, 3), (62, 60, 150, 4), (63, 100, 260, 5)])
+def test_sparse_strict_bit_identical(core, seed, m, ns, per_col):
+    lp, want = _oracle_sparse(core, seed, m, ns, per_col)
+    got = core.solve(lp, numerics=core.STRICT)
+    assert got.status == want.status
+    assert _log(got) == _log(want)
+    assert [p[3] for p in got.pivots] == [p[3] for p in want.pivots]
+    for name in ("x", "xbar", "z", "zbar"):
+        assert_bit_equal(getattr(got, name), getattr(want, name), name)
+    assert got.objective == want.objective
+
+
+@pytest.mark.parametrize("seed,m,ns,per_col", [(64, 60, 150, 4), (65, 150, 400, 5), (66, 256, 700, 6)])
+def test_sparse_fast_matches_pivot_sequence(core, seed, m, ns, per_col):
+    lp, want = _oracle_sparse(core, seed, m, ns, per_col)
+    got = core.solve(lp, numerics=core.FAST, poll_interval=16)
+    assert got.status == want.status
+    assert _log(got) == _log(want)
+    if want.status == "optimal":
+        assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
