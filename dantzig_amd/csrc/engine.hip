@@ -92,6 +92,7 @@ struct dzg_solver {
     int *rf_piv = nullptr, *rf_spos = nullptr, *rf_scode = nullptr, *rf_lpos = nullptr,
         *rf_lrow = nullptr, *rf_counts = nullptr;
     long long since_refactor = 0;
+    int prof_slot = -1; // phase path: event slot of the iteration being enqueued (-1: none)
     int64_t refactors = 0;
     // column sharding
     void *comm = nullptr;                  // ncclComm_t
@@ -504,6 +505,7 @@ static void collect_profile(dzg_solver *s, int slots_real)
     for (int slot = 0; slot < slots_real; ++slot)
         for (int cls = 0; cls < DZG_K_COUNT; ++cls) {
             if (!(s->opts.profile & (1 << cls))) continue;
+            if (s->d.csc && cls != DZG_K_PRICE) continue; // the phase path only stamps pricing
             float ms = 0.f;
             size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
             if (hipEventElapsedTime(&ms, s->ev[base], s->ev[base + 1]) == hipSuccess) {
@@ -564,12 +566,14 @@ static int run_fast(dzg_solver *s)
             TRY(shard_buffers(s));
             const size_t nb = sizeof(double) * (size_t)s->d.xstride;
             for (int b = 0; b < batch; ++b) {
+                s->prof_slot = s->opts.profile ? b : -1;
                 TRY(dzg_shard_phase1(s, s->xsend));
                 HIP_OK(hipMemcpyAsync(s->xrecv1, s->xsend, nb, hipMemcpyDeviceToDevice, s->st));
                 TRY(dzg_shard_phase2(s, s->xrecv1, s->xsend));
                 HIP_OK(hipMemcpyAsync(s->xrecv2, s->xsend, nb, hipMemcpyDeviceToDevice, s->st));
                 TRY(dzg_shard_phase3(s, s->xrecv2));
             }
+            s->prof_slot = -1;
         } else {
             for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
         }
@@ -670,7 +674,11 @@ extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *s
     dzg_launch_fast_select_prep(d, 2, 0, recv_dev, st);    // primal: FTRAN prep from the record
     dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, recv_dev, st);
     dzg_launch_fast_btran(d, st);
+    const bool prof = s->prof_slot >= 0 && (s->opts.profile & (1 << DZG_K_PRICE));
+    const size_t ev0 = prof ? ((size_t)s->prof_slot * DZG_K_COUNT + DZG_K_PRICE) * 2 : 0;
+    if (prof) hipEventRecord(s->ev[ev0], st);
     dzg_launch_price_fast(d, pk, st);                      // owned columns only
+    if (prof) hipEventRecord(s->ev[ev0 + 1], st);
     dzg_launch_shard_propose(d, 1, dzg_price_partials(pk), send_dev, st);
     return 0;
 }

@@ -357,19 +357,46 @@ __global__ __launch_bounds__(256) void k_price_csc(
     best.k = -1;
     price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, z, zbar);
     const int count = plist ? (int)ctl->nb_struct : q;
-    const int nthreads = gridDim.x * blockDim.x;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += nthreads) {
-        const int pos = plist ? plist[idx] : idx;
-        const int code = price_code(nonbasis, var_col, pos);
-        if (code < 0) continue;
-        double acc = 0.0; // Iterator::sum identity
-        const long long e1 = cptr[code - col0 + 1];
-        for (long long e = cptr[code - col0]; e < e1; ++e) {
-            const double p = cval[e] * -v[ridx[e]];
-            acc = acc + p;
+    // 8 lanes share one column: they fetch 8 consecutive stored entries at a time (coalesced
+    // 64-B / 32-B segments) and form the 8 products in parallel; the running sum then takes the
+    // products one by one in stored (ascending-row) order through shuffles, so the order of
+    // additions -- hence every bit of dz -- is the reference's.
+    const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int ngroups = (gridDim.x * blockDim.x) >> 3;
+    for (int idx0 = 0; idx0 < count; idx0 += ngroups) { // wave-uniform trip count
+        const int idx = idx0 + group;
+        int pos = -1, code = -1;
+        long long e0 = 0, e1 = 0;
+        if (idx < count) {
+            pos = plist ? plist[idx] : idx;
+            code = price_code(nonbasis, var_col, pos);
+            if (code >= 0) {
+                e0 = cptr[code - col0];
+                e1 = cptr[code - col0 + 1];
+            }
         }
-        dz[pos] = acc;
-        if (z) price_candidate(best, acc, pos, mu, z, zbar);
+        long long span = e1 - e0;
+#pragma unroll
+        for (int off = 32; off >= 8; off >>= 1) { // longest column among the wave's 8 groups
+            const long long o = __shfl_xor(span, off, DZG_WAVE);
+            span = o > span ? o : span;
+        }
+        double acc = 0.0; // Iterator::sum identity
+        for (long long base = 0; base < span; base += 8) {
+            const long long e = e0 + base + sub;
+            double p = 0.0;
+            if (e < e1) p = cval[e] * -v[ridx[e]];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double pt = __shfl(p, gbase + t, DZG_WAVE);
+                if (e0 + base + t < e1) acc = acc + pt;
+            }
+        }
+        if (code >= 0 && sub == 0) {
+            dz[pos] = acc;
+            if (z) price_candidate(best, acc, pos, mu, z, zbar);
+        }
     }
     price_publish(best, rz_r, rz_k);
 }
