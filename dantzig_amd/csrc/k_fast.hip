@@ -159,9 +159,16 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
             if (threadIdx.x == 0) beta[b] = wt[-1 - code];
             return;
         }
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) acc = fma(wt[i], a[i], acc);
-        acc = block_sum(acc);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int i = threadIdx.x;
+        for (; i + 3 * 256 < m; i += 4 * 256) { // four loads in flight per array and thread
+            a0 = fma(wt[i], a[i], a0);
+            a1 = fma(wt[i + 256], a[i + 256], a1);
+            a2 = fma(wt[i + 512], a[i + 512], a2);
+            a3 = fma(wt[i + 768], a[i + 768], a3);
+        }
+        for (; i < m; i += 256) a0 = fma(wt[i], a[i], a0);
+        double acc = block_sum((a0 + a1) + (a2 + a3));
         if (threadIdx.x == 0) beta[b] = acc;
     } else {
         if (code < 0) {
@@ -370,16 +377,8 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     if (!s_ok) return;
     const int vi = basis[p], vj = nonbasis[r];
     const int ci = var_col[vi], cj = var_col[vj];
-    // ---- eta append: Binv_new = Binv - u v^T, u = (dx - e_p)/dx_p
-    const double rdxp = 1.0 / dx[p];
-    double *wt = W + (long long)neta * ldw;
-    double *ut = U + (long long)neta * ldu; // eta t is one contiguous row of U and one of W
-    for (int i = tid; i < m; i += blockDim.x) {
-        const double d = dx[i];
-        ut[i] = (i == p ? d - 1.0 : d) * rdxp;
-        wt[i] = v[i];
-    }
-    __syncthreads();
+    // (the eta of this pivot, u = (dx - e_p)/dx_p and w = v, is appended by k_fast_update,
+    // which runs on the whole chip: here one workgroup only keeps the books)
     // ---- a leaving slack makes the column of its row dense: it was e_p
     if (ci < 0 && tid == 0) {
         const int k = s_k, rl = -1 - ci;
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
             if (ce != last) row[ce] = row[last];
             row[last] = 0.0;
         }
-        for (int t = tid; t <= neta; t += blockDim.x) W[(long long)t * ldw + re] = 0.0;
+        for (int t = tid; t < neta; t += blockDim.x) W[(long long)t * ldw + re] = 0.0;
         __syncthreads();
         if (tid == 0) {
             if (ce != last) {
@@ -471,10 +470,20 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
                                                      const int *__restrict__ nonbasis,
                                                      const int *__restrict__ var_col, int col0,
                                                      int col1, int sharded, double *fpx_r,
-                                                     int *fpx_k, double *fpz_r, int *fpz_k)
+                                                     int *fpx_k, double *fpz_r, int *fpz_k,
+                                                     const double *__restrict__ v,
+                                                     double *__restrict__ U, long long ldu,
+                                                     double *__restrict__ W, long long ldw)
 {
     if (ctl->status != DZG_RUNNING) return;
     const int p = ctl->leave_pos, r = ctl->enter_pos;
+    // eta of the pivot k_fast_pivot just booked (neta already counts it): u = (dx - e_p)/dx_p,
+    // w = v; if a slack entered, its row of W is structurally zero (its column became e_p)
+    const int teta = ctl->neta - 1;
+    const int wzero = ctl->enter_code < 0 ? -1 - ctl->enter_code : -1;
+    const double rdxp = only_partials ? 0.0 : 1.0 / dx[p];
+    double *ut = U + (long long)(teta < 0 ? 0 : teta) * ldu;
+    double *wt = W + (long long)(teta < 0 ? 0 : teta) * ldw;
     const double t = ctl->t, s = ctl->s, tbar = ctl->tbar, sbar = ctl->sbar;
     const int stride = gridDim.x * blockDim.x;
     DzgCand bx, bz;
@@ -489,6 +498,8 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
             xb = (i == p) ? tbar : xb - b;
             x[i] = xi;
             xbar[i] = xb;
+            ut[i] = (i == p ? d - 1.0 : d) * rdxp;
+            wt[i] = (i == wzero) ? 0.0 : v[i];
         }
         if (xb > 0.0) {
             DzgCand c;
@@ -882,7 +893,8 @@ void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
                        d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.nonbasis, d.var_col, d.col0, d.col1,
-                       d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k);
+                       d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.v, d.U, d.ldw, d.W,
+                       d.ldw);
 }
 
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
