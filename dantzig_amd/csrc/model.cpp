@@ -29,7 +29,11 @@ struct Row {
 
 struct Built {
     int64_t m = 0, n = 0, ns = 0;
-    std::vector<double> a; // column-major m x ns, lda = m
+    std::vector<double> a; // column-major m x ns, lda = m (dense mode)
+    bool sparse = false;   // large, sparse models: structural block kept CSC, never densified
+    std::vector<int64_t> col_ptr;
+    std::vector<int32_t> row_idx;
+    std::vector<double> val;
     std::vector<int64_t> var_col, basis, nonbasis, pos_var, neg_var;
     std::vector<double> c, x, z;
     double constant = 0.0;
@@ -55,7 +59,7 @@ bool valid(const dzg_model *md)
     return true;
 }
 
-void build(const dzg_model *md, Built &out)
+void build(const dzg_model *md, Built &out, bool allow_sparse)
 {
     const int64_t V = md->nvars;
     std::vector<int64_t> ord((size_t)V, -1);
@@ -145,11 +149,50 @@ void build(const dzg_model *md, Built &out)
             out.z.push_back(-out.c[(size_t)i]);
         }
     }
-    out.a.assign((size_t)(m * ns > 0 ? m * ns : 1), 0.0);
-    for (int64_t r = 0; r < m; ++r) {
-        const Row &row = rows[(size_t)r];
-        for (size_t e = 0; e + 1 < row.id.size(); ++e) // all but the slack
-            out.a[(size_t)(row.id[e] * m + r)] = row.coef[e];
+    // dense when small or dense; CSC when the m x ns block would be large and mostly zero
+    // (the reference densifies to m x n regardless, src/simplex.rs:62-81)
+    int64_t nterms_total = 0;
+    for (const Row &row : rows) nterms_total += (int64_t)row.id.size() - 1;
+    out.sparse = allow_sparse && m * ns >= (int64_t)1 << 22 && nterms_total * 4 < m * ns;
+    if (!out.sparse) {
+        out.a.assign((size_t)(m * ns > 0 ? m * ns : 1), 0.0);
+        for (int64_t r = 0; r < m; ++r) {
+            const Row &row = rows[(size_t)r];
+            for (size_t e = 0; e + 1 < row.id.size(); ++e) // all but the slack
+                out.a[(size_t)(row.id[e] * m + r)] = row.coef[e];
+        }
+    } else {
+        // rows are visited in ascending order, so every column's entries come out row-ascending;
+        // a variable repeated inside one row keeps its LAST coefficient (assignment semantics)
+        std::vector<int64_t> cnt((size_t)ns + 1, 0);
+        std::vector<int64_t> last_row((size_t)ns, -1);
+        for (int64_t r = 0; r < m; ++r) {
+            const Row &row = rows[(size_t)r];
+            for (size_t e = 0; e + 1 < row.id.size(); ++e)
+                if (last_row[(size_t)row.id[e]] != r) {
+                    last_row[(size_t)row.id[e]] = r;
+                    ++cnt[(size_t)row.id[e] + 1];
+                }
+        }
+        for (int64_t j = 0; j < ns; ++j) cnt[(size_t)j + 1] += cnt[(size_t)j];
+        out.col_ptr = cnt;
+        out.row_idx.assign((size_t)cnt[(size_t)ns] + 1, 0);
+        out.val.assign((size_t)cnt[(size_t)ns] + 1, 0.0);
+        std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+        std::fill(last_row.begin(), last_row.end(), -1);
+        std::vector<int64_t> slot_of((size_t)ns, -1);
+        for (int64_t r = 0; r < m; ++r) {
+            const Row &row = rows[(size_t)r];
+            for (size_t e = 0; e + 1 < row.id.size(); ++e) {
+                const int64_t j = row.id[e];
+                if (last_row[(size_t)j] != r) {
+                    last_row[(size_t)j] = r;
+                    slot_of[(size_t)j] = fill[(size_t)j]++;
+                    out.row_idx[(size_t)slot_of[(size_t)j]] = (int32_t)r;
+                }
+                out.val[(size_t)slot_of[(size_t)j]] = row.coef[e];
+            }
+        }
     }
     out.pos_var.assign((size_t)V, -1);
     out.neg_var.assign((size_t)V, -1);
@@ -166,7 +209,7 @@ extern "C" int dzg_build_standard_form(const dzg_model *md, dzg_stdform *out)
 {
     if (!out || !valid(md)) return DZG_E_ARG;
     Built b;
-    build(md, b);
+    build(md, b, false);
     if (!out->a && !out->var_col && !out->c) { // sizing call
         out->m = b.m;
         out->n = b.n;
@@ -200,7 +243,7 @@ extern "C" int dzg_model_solve(const dzg_model *md, const dzg_opts *opts, dzg_mo
 {
     if (!res || !valid(md)) return DZG_E_ARG;
     Built b;
-    build(md, b);
+    build(md, b, true);
     res->m = b.m;
     res->n = b.n;
     dzg_lp lp;
@@ -208,8 +251,13 @@ extern "C" int dzg_model_solve(const dzg_model *md, const dzg_opts *opts, dzg_mo
     lp.m = b.m;
     lp.n = b.n;
     lp.n_struct = b.ns;
-    lp.a = b.a.data();
+    lp.a = b.sparse ? nullptr : b.a.data();
     lp.lda = b.m > 0 ? b.m : 1;
+    if (b.sparse) {
+        lp.col_ptr = b.col_ptr.data();
+        lp.row_idx = b.row_idx.data();
+        lp.val = b.val.data();
+    }
     lp.var_col = b.var_col.data();
     lp.c = b.c.data();
     lp.constant = b.constant;

@@ -208,3 +208,63 @@ def test_python_kat_on_gpu(k):
     for name, want in exp["values"].items():
         assert sol[ns[name]] == want
     assert sol[dz.Variable.nonneg()] == 0.0  # unknown variable -> 0.0 (src/pyobjs.rs:163-165)
+
+
+# ------------------------------------------------------------------ larger user models on the GPU
+@pytest.mark.gpu
+def test_large_sparse_model_through_surface():
+    """1500 bounded variables, 600 sparse rows: the standard form is 3600 x 6600 and mostly
+    zero, so Level 2 hands the structural block over in CSC (never densified) and FAST numerics
+    solves it; the optimum is checked against an independent solver (scipy / HiGHS)."""
+    import scipy.sparse as sp
+    from scipy.optimize import linprog
+
+    rng = np.random.default_rng(3)
+    K, M, per_row = 1500, 600, 6
+    xs = [dz.Variable(lb=0.0, ub=10.0) for _ in range(K)]
+    c = rng.uniform(0.1, 1.0, K)
+    x0 = rng.uniform(0, 1, K)
+    a = sp.lil_matrix((M, K))
+    rows = []
+    for r in range(M):
+        idx = rng.choice(K, per_row, replace=False)
+        coef = rng.uniform(0.1, 1.0, per_row)
+        a[r, idx] = coef
+        rows.append((idx, coef, float(coef @ x0[idx]) + rng.uniform(0.1, 1)))
+    problem = dz.Maximize(sum(float(ci) * xi for ci, xi in zip(c, xs)))
+    problem.subject_to([sum(float(cf) * xs[i] for i, cf in zip(idx, coef)) <= b
+                        for idx, coef, b in rows])
+    ref = linprog(-c, A_ub=a.tocsr(), b_ub=[b for _, _, b in rows], bounds=(0, 10), method="highs")
+    sol = problem.solve()
+    assert sol._solution.numerics == "fast" and sol._solution.shape == (3600, 6600)
+    assert abs(sol.objective_value + ref.fun) <= 1e-9 * abs(ref.fun)
+    got = np.array([sol[x] for x in xs])
+    assert got.min() >= -1e-9 and got.max() <= 10 + 1e-9
+    assert (a.tocsr() @ got - np.array([b for _, _, b in rows])).max() <= 1e-7
+
+
+@pytest.mark.gpu
+def test_degenerate_transportation_model_through_surface():
+    """Integer data, heavy degeneracy (exact ties everywhere), 1270 rows: FAST numerics."""
+    from scipy.optimize import linprog
+
+    rng = np.random.default_rng(4)
+    S, D = 30, 40
+    supply = rng.integers(20, 60, S).astype(float)
+    demand = rng.integers(5, 25, D).astype(float)
+    cost = rng.integers(1, 20, (S, D)).astype(float)
+    x = [[dz.Variable.nonneg() for _ in range(D)] for _ in range(S)]
+    problem = dz.Minimize(sum(cost[i][j] * x[i][j] for i in range(S) for j in range(D)))
+    problem.subject_to([sum(x[i][j] for j in range(D)) <= supply[i] for i in range(S)]
+                       + [sum(x[i][j] for i in range(S)) >= demand[j] for j in range(D)])
+    a = np.zeros((S + D, S * D))
+    b = np.zeros(S + D)
+    for i in range(S):
+        a[i, i * D:(i + 1) * D] = 1
+        b[i] = supply[i]
+    for j in range(D):
+        a[S + j, j::D] = -1
+        b[S + j] = -demand[j]
+    ref = linprog(cost.ravel(), A_ub=a, b_ub=b, bounds=(0, None), method="highs")
+    sol = problem.solve()
+    assert abs(sol.objective_value - ref.fun) <= 1e-9 * abs(ref.fun)
