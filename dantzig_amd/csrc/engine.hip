@@ -240,7 +240,10 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     DzgDev &d = s->d;
     const int m = (int)lp->m, n = (int)lp->n, ns = (int)lp->n_struct, q = n - m;
     d.m = m; d.n = n; d.ns = ns; d.q = q;
-    d.lda = ((long long)m + 15) / 16 * 16;
+    // 16-B aligned columns; on tall matrices a column stride that is not a multiple of a large
+    // power of two spreads the 16 concurrent column streams of a wave over more HBM channels
+    // (+1.5-2 % on the pricing pass, profiles/r01_price_microbench_*.txt)
+    d.lda = ((long long)m + 15) / 16 * 16 + (m >= 2048 ? 272 : 0);
     if (d.lda == 0) d.lda = 16;
     d.eps = o.epsilon;
     d.world = o.world > 1 ? o.world : 1;

@@ -326,3 +326,18 @@ def test_sparse_fast_matches_pivot_sequence(core, seed, m, ns, per_col):
     assert _log(got) == _log(want)
     if want.status == "optimal":
         assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+
+
+# ------------------------------------------------------------------ parity at benchmark-scale sizes
+@pytest.mark.parametrize("seed,m,ns,pivots", [(1002, 1024, 2048, 60), (2002, 2048, 4096, 24)])
+def test_fast_matches_strict_pivots_at_scale(core, seed, m, ns, pivots):
+    """Sizes the CPU oracle cannot reach in test time: STRICT numerics (bit-identical to the
+    oracle wherever both can run) is the arbiter, FAST must take the same first pivots."""
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    strict = core.solve(lp, numerics=core.STRICT, max_iter=pivots)
+    fast = core.solve(lp, numerics=core.FAST, max_iter=pivots)
+    assert strict.status == fast.status == "iter_limit"
+    assert _log(fast) == _log(strict)
+    assert np.allclose([p[3] for p in fast.pivots], [p[3] for p in strict.pivots], rtol=1e-9)
+    assert np.allclose(fast.x, strict.x, rtol=1e-8, atol=1e-9)
