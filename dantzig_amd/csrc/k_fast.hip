@@ -335,31 +335,44 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const double *__restrict__ dz, const double *__restrict__ v, int *basis, int *nonbasis,
     const int *__restrict__ var_col, double *binv, long long ldb, int *drow, int *dslot,
     double *U, long long ldu, double *W, long long ldw, int *plist, int *pslot, int col0, int col1,
-    const long long *__restrict__ cptr, int *log_kind, int *log_enter,
-    int *log_leave, double *log_mu, long long log_cap)
+    const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
+    double *log_mu, long long log_cap)
 {
-    __shared__ int s_ok, s_k, s_ce, s_last;
+    __shared__ int s_ok, s_k, s_ce, s_last, s_ci, s_cj;
     if (ctl->status != DZG_RUNNING) return;
     const int tid = threadIdx.x;
-    const int p = ctl->leave_pos, r = ctl->enter_pos;
-    const int neta = ctl->neta;
+    // hop 1: the control block (one cache line)
+    const int p = ctl->leave_pos, r = ctl->enter_pos, neta = ctl->neta;
+    const bool rec = ctl->use_record != 0;
+    const long long s0 = ctl->nb_struct;
+    // hop 2: everything addressed by p, r -- issued together, used below
+    int vi = 0, vj = 0, idx_r = 0, lastpos = 0;
+    double xp = 0, xbp = 0, dxp = 1, zr = 0, zbr = 0, dzr = 1;
     if (tid == 0) {
+        vi = basis[p];
+        vj = nonbasis[r];
+        xp = x[p];
+        xbp = xbar[p];
+        dxp = dx[p];
+        zr = rec ? ctl->zr : z[r];
+        zbr = rec ? ctl->zbar_r : zbar[r];
+        dzr = rec ? ctl->dz_r : dz[r];
+        idx_r = pslot[r];
+        lastpos = s0 > 0 ? plist[s0 - 1] : 0;
+        // hop 3: the two column codes
+        const int ci = var_col[vi], cj = var_col[vj];
         int ok = 1;
-        // sharded: z, zbar, dz of the entering position come from its owner's exchange record
-        const bool rec = ctl->use_record != 0;
-        const double zr = rec ? ctl->zr : z[r], zbr = rec ? ctl->zbar_r : zbar[r];
-        const double dzr = rec ? ctl->dz_r : dz[r];
-        const double t = dzg_safe_divide(x[p], dx[p], &ok);
+        const double t = dzg_safe_divide(xp, dxp, &ok);
         const double s = dzg_safe_divide(zr, dzr, &ok);
-        const double tbar = dzg_safe_divide(xbar[p], dx[p], &ok);
+        const double tbar = dzg_safe_divide(xbp, dxp, &ok);
         const double sbar = dzg_safe_divide(zbr, dzr, &ok);
         if (neta >= R_) ok = 0; // the host flushes every DZG_RMAX pivots; never reached
         // the pivot element is known twice: dx_p = (B^-1 a_j)_p from FTRAN and -dz_r = v . a_j
         // from BTRAN + pricing.  Their disagreement measures what the explicit inverse lost.
         {
-            const double a1 = fabs(dx[p]), a2 = fabs(dzr);
+            const double a1 = fabs(dxp), a2 = fabs(dzr);
             const double den = a1 > a2 ? a1 : a2;
-            const double err = den > 0.0 ? fabs(dx[p] + dzr) / den : 0.0;
+            const double err = den > 0.0 ? fabs(dxp + dzr) / den : 0.0;
             if (err > ctl->max_pivot_err) ctl->max_pivot_err = err;
         }
         if (ok) {
@@ -372,11 +385,12 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
         }
         s_ok = ok;
         s_k = ctl->ncompact;
+        s_ci = ci;
+        s_cj = cj;
     }
     __syncthreads();
     if (!s_ok) return;
-    const int vi = basis[p], vj = nonbasis[r];
-    const int ci = var_col[vi], cj = var_col[vj];
+    const int ci = s_ci, cj = s_cj;
     // (the eta of this pivot, u = (dx - e_p)/dx_p and w = v, is appended by k_fast_update,
     // which runs on the whole chip: here one workgroup only keeps the books)
     // ---- a leaving slack makes the column of its row dense: it was e_p
@@ -387,9 +401,9 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
         binv[(long long)p * ldb + k] = 1.0; // columns >= ncompact are kept zero
         s_k = k + 1;
     }
-    __syncthreads();
     // ---- an entering slack makes the column of its row the unit vector e_p again
     if (cj < 0) {
+        __syncthreads();
         const int re = -1 - cj;
         if (tid == 0) {
             s_ce = dslot[re];
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
         log_leave[it] = vi;
         log_mu[it] = ctl->mu;
     }
-    long long s = ctl->nb_struct;
+    long long s = s0;
     // algorithmic bytes of this iteration's pricing pass; sparse: 12 B per stored
     // entry of the nonbasic structural columns + their column pointers
     if (cptr)
@@ -440,9 +454,8 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
         if (own_i) ctl->nb_nnz += cptr[ci - col0 + 1] - cptr[ci - col0];
     }
     if (own_j && !own_i) { // an owned structural column left the nonbasic set
-        const int idx = pslot[r], lastpos = plist[s - 1];
-        plist[idx] = lastpos;
-        pslot[lastpos] = idx;
+        plist[idx_r] = lastpos;
+        pslot[lastpos] = idx_r;
         pslot[r] = -1;
         --s;
     } else if (!own_j && own_i) {

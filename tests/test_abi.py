@@ -1,0 +1,115 @@
+"""The C-ABI library loads on a CPU-only host and exports every entry point that
+include/dantzig_amd.h declares; host-only entry points work without a GPU; device entry points
+fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dantzig_amd import _ffi, core
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "dantzig_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dzg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_expects():
+    names = declared_functions()
+    assert len(names) >= 25
+    assert set(_ffi.EXPORTS) <= set(names)
+
+
+@pytest.mark.parametrize("name", declared_functions())
+def test_symbol_is_exported(name):
+    assert hasattr(_ffi.lib(), name), f"{name} is declared in the header but not exported"
+
+
+def test_abi_version_and_status_strings():
+    lib = _ffi.lib()
+    assert lib.dzg_abi_version() == 1
+    assert _ffi.status_str(0) == "optimal" and _ffi.status_str(1) == "unbounded"
+    assert _ffi.status_str(2) == "infeasible" and _ffi.status_str(-1) == "device_error"
+    o = _ffi.default_opts()
+    assert (o.numerics, o.price_kernel, o.auto_strict_rows, o.poll_interval) == (2, 0, 192, 32)
+    assert o.epsilon == 1e-12 and o.max_iter == 10_000_000 and o.refactor_interval == 0
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof as gcc lays the header's structs out vs the ctypes mirrors: a drifted
+    mirror would corrupt arguments silently."""
+    import subprocess
+
+    structs = {"dzg_lp": _ffi.Lp, "dzg_opts": _ffi.Opts, "dzg_pivot": _ffi.Pivot,
+               "dzg_result": _ffi.Result, "dzg_model": _ffi.Model,
+               "dzg_model_result": _ffi.ModelResult, "dzg_stdform": _ffi.StdForm,
+               "dzg_candidate": _ffi.Candidate}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dantzig_amd.h"',
+             'int main(void) {']
+    for cname, mirror in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for field, _ in mirror._fields_:
+            lines.append(f'printf("{cname}.{field} %zu\\n", offsetof({cname}, {field}));')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, mirror in structs.items():
+        assert int(got[cname]) == C.sizeof(mirror), cname
+        for field, _ in mirror._fields_:
+            assert int(got[f"{cname}.{field}"]) == getattr(mirror, field).offset, f"{cname}.{field}"
+
+
+def test_generators_are_deterministic_host_code():
+    a1, b1, c1 = core.gen_dense_lp(seed=5, m=7, n_struct=11)
+    a2, b2, c2 = core.gen_dense_lp(seed=5, m=7, n_struct=11)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(c1, c2)
+    assert a1.shape == (7, 11) and np.abs(a1).max() < 1.0
+    # b = A x0 + rb with x0, rb in [0,1): recompute in the same ascending order
+    assert np.all(np.isfinite(b1)) and np.all(np.isfinite(c1))
+    cp, ri, val, b, c = core.gen_sparse_lp(9, 20, 30, 4)
+    assert cp.tolist() == list(range(0, 121, 4)) and len(ri) == 120
+    for j in range(30):
+        rows = ri[cp[j]:cp[j + 1]]
+        assert np.all(np.diff(rows) > 0) and rows.min() >= 0 and rows.max() < 20
+    assert np.all(val != 0.0)
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    if _ffi.lib().dzg_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    a, b, c = core.gen_dense_lp(seed=1, m=4, n_struct=6)
+    with pytest.raises(_ffi.DantzigAmdError):
+        core.solve(core.CoreLP.from_inequality_form(a, b, c))
+    with pytest.raises(_ffi.DantzigAmdError):
+        core.lu_solve(np.eye(3), np.ones(3))
+    with pytest.raises(_ffi.DantzigAmdError):
+        core.neg_t_dot(np.eye(3), [0, 1], np.ones(3))
+
+
+def test_malformed_lps_are_rejected_before_any_device_work():
+    a, b, c = core.gen_dense_lp(seed=1, m=4, n_struct=6)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    bad = core.CoreLP(a=lp.a, c=lp.c, basis=lp.basis.copy(), nonbasis=lp.nonbasis.copy(),
+                      x=lp.x, z=lp.z)
+    bad.basis[0] = bad.nonbasis[0]  # not a partition of 0..n-1 any more
+    k = dict(a=np.ascontiguousarray(np.asarray(bad.a).T), c=_ffi.f64(bad.c),
+             basis=_ffi.i64(bad.basis), nonbasis=_ffi.i64(bad.nonbasis), x=_ffi.f64(bad.x),
+             z=_ffi.f64(bad.z))
+    p = _ffi.ptr
+    c_lp = _ffi.Lp(4, 10, 6, p(k["a"]), 4, None, p(k["c"]), 0.0, p(k["basis"]), p(k["nonbasis"]),
+                   p(k["x"]), p(k["z"]), None, None, None)
+    h = C.c_void_p(None)
+    rc = _ffi.lib().dzg_solver_create(C.byref(c_lp), None, C.byref(h))
+    assert rc == _ffi.E_ARG and not h.value
+    assert b"partition" in _ffi.lib().dzg_last_error()
+    c_lp.lda = 3  # lda < m
+    k["basis"][0] = 6
+    assert _ffi.lib().dzg_solver_create(C.byref(c_lp), None, C.byref(h)) == _ffi.E_ARG

@@ -341,3 +341,30 @@ def test_fast_matches_strict_pivots_at_scale(core, seed, m, ns, pivots):
     assert _log(fast) == _log(strict)
     assert np.allclose([p[3] for p in fast.pivots], [p[3] for p in strict.pivots], rtol=1e-9)
     assert np.allclose(fast.x, strict.x, rtol=1e-8, atol=1e-9)
+
+
+# ------------------------------------------------------------------ outcomes and edge shapes
+@pytest.mark.parametrize("numerics", ["strict", "fast"])
+def test_unbounded_infeasible_and_degenerate_shapes(core, numerics):
+    num = core.STRICT if numerics == "strict" else core.FAST
+    # max x0 + x1  st  -x0 + x1 <= 1  (unbounded along x0), x >= 0
+    lp = core.CoreLP.from_inequality_form(np.array([[-1.0, 1.0]]), [1.0], [1.0, 1.0])
+    assert core.solve(lp, numerics=num).status == "unbounded"
+    # x0 + x1 <= -1 with x >= 0 is empty
+    lp = core.CoreLP.from_inequality_form(np.array([[1.0, 1.0]]), [-1.0], [1.0, -1.0])
+    assert core.solve(lp, numerics=num).status == "infeasible"
+    # already optimal at the slack basis: no pivot at all
+    lp = core.CoreLP.from_inequality_form(np.array([[1.0, 2.0], [3.0, 1.0]]), [1.0, 2.0], [-1.0, -2.0])
+    res = core.solve(lp, numerics=num)
+    assert res.status == "optimal" and res.iterations == 0 and res.objective == 0.0
+    # no structural column at all (only slacks), feasible rhs
+    lp = core.CoreLP(a=np.zeros((3, 0)), c=np.zeros(3), basis=np.arange(3), nonbasis=np.zeros(0, np.int64),
+                     x=np.array([1.0, 2.0, 3.0]), z=np.zeros(0))
+    res = core.solve(lp, numerics=num)
+    assert res.status == "optimal" and res.iterations == 0
+    # a single row and a single column
+    lp = core.CoreLP.from_inequality_form(np.array([[2.0]]), [4.0], [3.0])
+    res = core.solve(lp, numerics=num)
+    want = ora.simplex_solve(ora.stdform_from_dense(np.array([[2.0]]), np.array([4.0]), np.array([3.0])))
+    assert res.status == want.status == "optimal" and res.objective == want.objective == 6.0
+    assert _log(res) == _log(want)
