@@ -357,14 +357,20 @@ def test_unbounded_infeasible_and_degenerate_shapes(core, numerics):
     lp = core.CoreLP.from_inequality_form(np.array([[1.0, 2.0], [3.0, 1.0]]), [1.0, 2.0], [-1.0, -2.0])
     res = core.solve(lp, numerics=num)
     assert res.status == "optimal" and res.iterations == 0 and res.objective == 0.0
-    # no structural column at all (only slacks), feasible rhs
+    # no structural column at all (only slacks): the reference takes the one-sided branch of
+    # status() (src/simplex.rs:299-303, no optimality test), its dual ratio test over an empty
+    # set finds nothing and it reports Infeasible -- a reference quirk the engine reproduces
     lp = core.CoreLP(a=np.zeros((3, 0)), c=np.zeros(3), basis=np.arange(3), nonbasis=np.zeros(0, np.int64),
                      x=np.array([1.0, 2.0, 3.0]), z=np.zeros(0))
     res = core.solve(lp, numerics=num)
-    assert res.status == "optimal" and res.iterations == 0
-    # a single row and a single column
+    want = ora.simplex_solve(ora.stdform_from_dense(np.zeros((3, 0)), np.array([1.0, 2.0, 3.0]), np.zeros(0)))
+    assert res.status == want.status == "infeasible" and res.iterations == 0
+    # a single row and a single column entered at the core boundary (no x- column, no bound
+    # row): after one pivot zbar <= 0 everywhere, status() takes its one-sided branch without
+    # an optimality test (src/simplex.rs:299-303) and the reference answers Infeasible although
+    # x = 2 is optimal -- the engine must answer what the reference answers
     lp = core.CoreLP.from_inequality_form(np.array([[2.0]]), [4.0], [3.0])
     res = core.solve(lp, numerics=num)
     want = ora.simplex_solve(ora.stdform_from_dense(np.array([[2.0]]), np.array([4.0]), np.array([3.0])))
-    assert res.status == want.status == "optimal" and res.objective == want.objective == 6.0
+    assert res.status == want.status == "infeasible" and res.objective == want.objective == 6.0
     assert _log(res) == _log(want)
