@@ -136,7 +136,7 @@ struct DzgDev {
     // state
     int *basis, *nonbasis; // m, q
     double *x, *xbar, *z, *zbar; // m, m, q, q
-    double *dx, *dz, *v, *acol, *w; // m, q, m, m, m
+    double *dx, *dz, *v, *acol; // m, q, m (+2 zero pads), m
     DzgCtl *ctl;
     // log
     int *log_kind, *log_enter, *log_leave;

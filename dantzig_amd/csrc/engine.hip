@@ -341,7 +341,6 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     TRY(dev_alloc(s, &d.z, (size_t)q)); TRY(dev_alloc(s, &d.zbar, (size_t)q));
     TRY(dev_alloc(s, &d.dx, (size_t)m)); TRY(dev_alloc(s, &d.dz, (size_t)q));
     TRY(dev_alloc(s, &d.v, (size_t)m + 2)); TRY(dev_alloc(s, &d.acol, (size_t)m));
-    TRY(dev_alloc(s, &d.w, (size_t)m + 2));
     std::vector<double> ones((size_t)((m > q ? m : q) + 1), 1.0);
     if (m > 0) {
         HIP_OK(hipMemcpyAsync(d.x, lp->x, sizeof(double) * m, hipMemcpyHostToDevice, s->st));
@@ -352,7 +351,6 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         HIP_OK(hipMemcpyAsync(d.zbar, ones.data(), sizeof(double) * q, hipMemcpyHostToDevice, s->st));
     }
     HIP_OK(hipMemsetAsync(d.v, 0, sizeof(double) * ((size_t)m + 2), s->st));
-    HIP_OK(hipMemsetAsync(d.w, 0, sizeof(double) * ((size_t)m + 2), s->st));
     s->c_host.assign(lp->c, lp->c + n);
     s->constant = lp->constant;
 

@@ -85,7 +85,7 @@ __device__ __forceinline__ void price_publish(DzgCand best, double *__restrict__
 // Engine mode: plist != nullptr, count = ctl->nb_struct.  Raw mode (parity tests):
 // plist == nullptr, every position 0..q-1 is a column, codes may be negative.
 // ---------------------------------------------------------------------------------
-template <int CW, int DEPTH = 3, int DBG = 0, bool NT = true>
+template <int CW, int DEPTH = 2, int DBG = 0, bool NT = true>
 __global__ __launch_bounds__(256) void k_price_seq2(
     const DzgCtl *ctl, const double *__restrict__ A, long long lda, int m, int q,
     const int *__restrict__ plist, const int *__restrict__ nonbasis,
