@@ -506,7 +506,8 @@ static void collect_profile(dzg_solver *s, int slots_real)
     for (int slot = 0; slot < slots_real; ++slot)
         for (int cls = 0; cls < DZG_K_COUNT; ++cls) {
             if (!(s->opts.profile & (1 << cls))) continue;
-            if (s->d.csc && cls != DZG_K_PRICE) continue; // the phase path only stamps pricing
+            if ((s->d.csc || s->d.world > 1 || s->comm) && cls != DZG_K_PRICE)
+                continue; // the phase path only stamps pricing
             float ms = 0.f;
             size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
             if (hipEventElapsedTime(&ms, s->ev[base], s->ev[base + 1]) == hipSuccess) {
@@ -583,6 +584,15 @@ static int run_fast(dzg_solver *s)
         HIP_OK(hipGetLastError());
         collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
+        // health: the pivot element computed by FTRAN and by BTRAN + pricing must agree
+        if (s->h_ctl->max_pivot_err > 1e-9 && s->rfG && s->since_refactor > 0) {
+            TRY(refactor_now(s)); // sheds the accumulated rounding, then carries on
+        } else if (s->h_ctl->max_pivot_err > 1e-4 && !s->rfG) {
+            int st = DZG_SINGULAR; // no refactor workspace: stop rather than wander
+            HIP_OK(hipMemcpy(&s->d.ctl->status, &st, sizeof(int), hipMemcpyHostToDevice));
+            s->h_ctl->status = st;
+            break;
+        }
     }
     return 0;
 }
@@ -759,7 +769,9 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
     const size_t n = (size_t)s->d.xstride;
     auto t0 = std::chrono::steady_clock::now();
     for (;;) {
+        const long long before = s->h_ctl->iter;
         for (int b = 0; b < s->opts.poll_interval; ++b) {
+            s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
             if (r.AllGather(s->xsend, s->xrecv1, n, kNcclFloat64, s->comm, s->st) != 0)
                 return fail(DZG_E_DEVICE, "ncclAllGather (exchange 1)");
@@ -768,8 +780,10 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
                 return fail(DZG_E_DEVICE, "ncclAllGather (exchange 2)");
             TRY(dzg_shard_phase3(s, s->xrecv2));
         }
+        s->prof_slot = -1;
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
+        collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
     }
     s->solve_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

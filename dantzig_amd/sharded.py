@@ -95,7 +95,8 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
     a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
     lp = core.CoreLP.from_inequality_form(a, b, c)
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[args.price]
-    solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price)
+    solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price,
+                           profile=1 << _ffi.K_PRICE)
     del a, lp
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
@@ -107,6 +108,7 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
     if args.warmup > 0:
         status = solver.run(args.warmup)
     it0 = solver.poll()[1]          # poll synchronises the stream
+    r_warm = solver.result(log=False)
     dist.barrier()
     t0 = time.perf_counter()
     if status == "iter_limit":
@@ -137,7 +139,18 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
                 "exchanges_per_iteration": 2, "record_bytes": record_bytes,
                 "collective": "ncclAllGather (RCCL) of one record per rank",
             },
-            "roofline": None, "cpu_baseline": None,
+            "roofline": {
+                "bound": "hbm", "kernel": "pricing kernel of rank 0 (its column block only)",
+                "achieved": ((res.price_bytes - r_warm.price_bytes) / 1e9)
+                / max((res.kernel_ms["price"] - r_warm.kernel_ms["price"]) / 1e3, 1e-12),
+                "peak": 8000.0, "unit": "GB/s",
+                "frac": ((res.price_bytes - r_warm.price_bytes) / 1e9)
+                / max((res.kernel_ms["price"] - r_warm.kernel_ms["price"]) / 1e3, 1e-12) / 8000.0,
+                "traffic": None,
+                "avg_launch_us": 1e3 * (res.kernel_ms["price"] - r_warm.kernel_ms["price"])
+                / max(res.kernel_launches["price"] - r_warm.kernel_launches["price"], 1),
+            },
+            "cpu_baseline": None,
             "pricing_bytes_all_ranks": float(pb.item()),
         }))
     dist.destroy_process_group()
