@@ -118,7 +118,7 @@ def main() -> int:
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the column-sharded RCCL path even with one rank (rehearsal)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
-    ap.add_argument("--cpu-sample-pivots", type=int, default=40)
+    ap.add_argument("--cpu-sample-pivots", type=int, default=100)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

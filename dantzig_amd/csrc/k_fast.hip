@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
     const double *__restrict__ W, long long ldw, const int *__restrict__ drow,
     double *__restrict__ ag, double *__restrict__ beta, double eps)
 {
-    if (ctl->status != DZG_RUNNING) return;
+    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    if (c.status != DZG_RUNNING) return;
     int epos;
     if (MODE == 0) {
         const DzgCand cj = reduce_partials(fpz_r, fpz_k, DZG_NB_UPD);
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
             if (lead) ctl->status = DZG_PANIC;
             return;
         }
-        if (ctl->iter >= ctl->iter_stop) {
+        if (c.iter >= c.iter_stop) {
             if (lead) ctl->status = DZG_ITER_LIMIT;
             return;
         }
@@ -134,10 +135,10 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         if (kind != DZG_STEP_PRIMAL) return;
         epos = cj.k;
     } else if (MODE == 2) { // sharded: k_shard_decide already published the selection
-        if (ctl->kind != need_kind) return;
-        epos = ctl->enter_pos;
+        if (c.kind != need_kind) return;
+        epos = c.enter_pos;
     } else {
-        if (ctl->kind != DZG_STEP_DUAL) return;
+        if (c.kind != DZG_STEP_DUAL) return;
         const DzgCand c = reduce_partials(rz_r, rz_k, nrz);
         if (c.k < 0) {
             if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status = DZG_INFEASIBLE; // :325
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_pos = epos;
     }
     // ---- FTRAN preparation for the entering variable
-    const int code = MODE == 2 ? ctl->enter_code : var_col[nonbasis[epos]];
+    const int code = MODE == 2 ? c.enter_code : var_col[nonbasis[epos]];
     if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
-    const double *a = dzg_enter_col(ctl, code, A, lda, col0, xrecv, xstride);
-    const int neta = ctl->neta, k = ctl->ncompact;
+    const double *a = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
+    const int neta = c.neta, k = c.ncompact;
     const int b = blockIdx.x;
     if (b < R_) {
         if (b >= neta) return;
@@ -264,18 +265,19 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
     double *__restrict__ rx_r, int *__restrict__ rx_k)
 {
-    if (ctl->status != DZG_RUNNING || ctl->kind != need_kind) return;
-    const int k = ctl->ncompact, neta = ctl->neta;
-    const int code = ctl->enter_code;
-    const double *acolp = dzg_enter_col(ctl, code, A, lda, col0, xrecv, xstride);
+    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    if (c.status != DZG_RUNNING || c.kind != need_kind) return;
+    const int k = c.ncompact, neta = c.neta;
+    const int code = c.enter_code;
+    const double *acolp = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
     DzgCand best;
     best.r = 0.0;
     best.k = -1;
     if (k > 512)
-        gemv_rows<64>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
+        gemv_rows<64>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
                       var_col, x, xbar, dx, best);
     else
-        gemv_rows<16>(ctl, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
+        gemv_rows<16>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
                       var_col, x, xbar, dx, best);
     if (need_kind == DZG_STEP_PRIMAL) {
         best = dzg_block_best(best);
@@ -298,9 +300,10 @@ __global__ __launch_bounds__(256) void k_fast_btran(
     const double *__restrict__ rx_r, const int *__restrict__ rx_k, double *__restrict__ v)
 {
     __shared__ double s_up[R_];
-    if (ctl->status != DZG_RUNNING) return;
+    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    if (c.status != DZG_RUNNING) return;
     int p;
-    if (ctl->kind == DZG_STEP_PRIMAL) {
+    if (c.kind == DZG_STEP_PRIMAL) {
         const DzgCand c = reduce_partials(rx_r, rx_k, DZG_NB_GEMV);
         if (c.k < 0) {
             if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status = DZG_UNBOUNDED;
@@ -309,9 +312,9 @@ __global__ __launch_bounds__(256) void k_fast_btran(
         p = c.k;
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl->leave_pos = p;
     } else {
-        p = ctl->leave_pos;
+        p = c.leave_pos;
     }
-    const int neta = ctl->neta;
+    const int neta = c.neta;
     if (threadIdx.x < R_) s_up[threadIdx.x] = threadIdx.x < neta ? U[(long long)threadIdx.x * ldu + p] : 0.0;
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,24 +342,23 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     double *log_mu, long long log_cap)
 {
     __shared__ int s_ok, s_k, s_ce, s_last, s_ci, s_cj;
-    if (ctl->status != DZG_RUNNING) return;
+    // hop 1: the whole control block in one go (a couple of cache lines); every later decision
+    // uses this snapshot, and only the fields that change are written back at the end
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING) return;
     const int tid = threadIdx.x;
-    // hop 1: the control block (one cache line)
-    const int p = ctl->leave_pos, r = ctl->enter_pos, neta = ctl->neta;
-    const bool rec = ctl->use_record != 0;
-    const long long s0 = ctl->nb_struct;
+    const int p = c.leave_pos, r = c.enter_pos, neta = c.neta;
+    const bool rec = c.use_record != 0;
+    const long long s0 = c.nb_struct;
     // hop 2: everything addressed by p, r -- issued together, used below
     int vi = 0, vj = 0, idx_r = 0, lastpos = 0;
-    double xp = 0, xbp = 0, dxp = 1, zr = 0, zbr = 0, dzr = 1;
+    double max_err = c.max_pivot_err;
     if (tid == 0) {
         vi = basis[p];
         vj = nonbasis[r];
-        xp = x[p];
-        xbp = xbar[p];
-        dxp = dx[p];
-        zr = rec ? ctl->zr : z[r];
-        zbr = rec ? ctl->zbar_r : zbar[r];
-        dzr = rec ? ctl->dz_r : dz[r];
+        const double xp = x[p], xbp = xbar[p], dxp = dx[p];
+        const double zr = rec ? c.zr : z[r], zbr = rec ? c.zbar_r : zbar[r];
+        const double dzr = rec ? c.dz_r : dz[r];
         idx_r = pslot[r];
         lastpos = s0 > 0 ? plist[s0 - 1] : 0;
         // hop 3: the two column codes
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
             const double a1 = fabs(dxp), a2 = fabs(dzr);
             const double den = a1 > a2 ? a1 : a2;
             const double err = den > 0.0 ? fabs(dxp + dzr) / den : 0.0;
-            if (err > ctl->max_pivot_err) ctl->max_pivot_err = err;
+            if (err > max_err) max_err = err;
         }
         if (ok) {
             ctl->t = t;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
             ctl->status = DZG_PANIC; // assert in safe_divide, src/simplex.rs:466
         }
         s_ok = ok;
-        s_k = ctl->ncompact;
+        s_k = c.ncompact;
         s_ci = ci;
         s_cj = cj;
     }
@@ -430,28 +432,31 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     }
     if (tid != 0) return;
     // ---- swap, log, counters (single lane)
-    const long long it = ctl->iter;
+    const long long it = c.iter;
     if (it < log_cap) {
-        log_kind[it] = ctl->kind;
+        log_kind[it] = c.kind;
         log_enter[it] = vj;
         log_leave[it] = vi;
-        log_mu[it] = ctl->mu;
+        log_mu[it] = c.mu;
     }
     long long s = s0;
     // algorithmic bytes of this iteration's pricing pass; sparse: 12 B per stored
     // entry of the nonbasic structural columns + their column pointers
+    double bytes = c.price_bytes;
     if (cptr)
-        ctl->price_bytes += 12.0 * (double)ctl->nb_nnz + 4.0 * (double)(s + 1) + 8.0 * (double)m +
-                            32.0 * (double)q;
+        bytes += 12.0 * (double)c.nb_nnz + 4.0 * (double)(s + 1) + 8.0 * (double)m + 32.0 * (double)q;
     else
-        ctl->price_bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
+        bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
+    ctl->price_bytes = bytes;
     basis[p] = vj;
     nonbasis[r] = vi;
     // nonbasic position r now holds vi instead of vj; the list only tracks OWNED columns
     const bool own_j = cj >= col0 && cj < col1, own_i = ci >= col0 && ci < col1;
     if (cptr) {
-        if (own_j) ctl->nb_nnz -= cptr[cj - col0 + 1] - cptr[cj - col0];
-        if (own_i) ctl->nb_nnz += cptr[ci - col0 + 1] - cptr[ci - col0];
+        long long nnz = c.nb_nnz;
+        if (own_j) nnz -= cptr[cj - col0 + 1] - cptr[cj - col0];
+        if (own_i) nnz += cptr[ci - col0 + 1] - cptr[ci - col0];
+        ctl->nb_nnz = nnz;
     }
     if (own_j && !own_i) { // an owned structural column left the nonbasic set
         plist[idx_r] = lastpos;
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     ctl->leave_var = vi;
     ctl->ncompact = s_k;
     ctl->neta = neta + 1;
+    ctl->max_pivot_err = max_err;
     ctl->iter = it + 1;
 }
 
@@ -488,16 +494,17 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
                                                      double *__restrict__ U, long long ldu,
                                                      double *__restrict__ W, long long ldw)
 {
-    if (ctl->status != DZG_RUNNING) return;
-    const int p = ctl->leave_pos, r = ctl->enter_pos;
+    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    if (c.status != DZG_RUNNING) return;
+    const int p = c.leave_pos, r = c.enter_pos;
     // eta of the pivot k_fast_pivot just booked (neta already counts it): u = (dx - e_p)/dx_p,
     // w = v; if a slack entered, its row of W is structurally zero (its column became e_p)
-    const int teta = ctl->neta - 1;
-    const int wzero = ctl->enter_code < 0 ? -1 - ctl->enter_code : -1;
+    const int teta = c.neta - 1;
+    const int wzero = c.enter_code < 0 ? -1 - c.enter_code : -1;
     const double rdxp = only_partials ? 0.0 : 1.0 / dx[p];
     double *ut = U + (long long)(teta < 0 ? 0 : teta) * ldu;
     double *wt = W + (long long)(teta < 0 ? 0 : teta) * ldw;
-    const double t = ctl->t, s = ctl->s, tbar = ctl->tbar, sbar = ctl->sbar;
+    const double t = c.t, s = c.s, tbar = c.tbar, sbar = c.sbar;
     const int stride = gridDim.x * blockDim.x;
     DzgCand bx, bz;
     bx.r = bz.r = 0.0;
