@@ -195,6 +195,7 @@ const int kNcclFloat64 = 8;
 
 static void shard_comm_destroy(dzg_solver *s);
 static int shard_buffers(dzg_solver *s);
+static int refactor_now(dzg_solver *s);
 
 extern "C" void dzg_solver_destroy(dzg_solver *s)
 {
@@ -379,14 +380,19 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     *s->h_ctl = c0;
 
     if (s->numerics == DZG_NUMERICS_FAST) {
-        std::vector<char> row_seen((size_t)(m ? m : 1), 0);
-        for (int p = 0; p < m; ++p) {
-            const int code = var_col[basis[p]];
-            if (code >= 0 || row_seen[(size_t)(-1 - code)])
-                return fail(DZG_E_ARG, "FAST numerics starts from the slack basis (as Simplex::new "
-                                       "builds it); use STRICT for an arbitrary starting basis");
-            row_seen[(size_t)(-1 - code)] = 1;
+        // the slack basis of Simplex::new needs no factorisation (Binv0 starts empty); any other
+        // starting basis (warm start) is factorised on the device before the first iteration
+        bool slack_basis = true;
+        for (int p = 0; p < m; ++p)
+            if (var_col[basis[p]] >= 0) slack_basis = false;
+        if (!slack_basis) {
+            if (d.csc || d.world > 1)
+                return fail(DZG_E_ARG, "a non-slack starting basis needs dense, unsharded input "
+                                       "in FAST numerics (use STRICT otherwise)");
+            if (o.refactor_interval == 0) o.refactor_interval = -1; // reserve the workspace
+            s->opts.refactor_interval = o.refactor_interval;
         }
+        const bool needs_initial_refactor = !slack_basis;
         // row stride: not a multiple of a large power of two, so that the first k columns of
         // consecutive rows do not all land on the same HBM channels
         d.ldb = ((long long)m + 15) / 16 * 16 + 32;
@@ -415,6 +421,9 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         }
         dzg_launch_fast_init(d, s->st);
         dzg_launch_fast_update(d, 1, s->st); // first-pivot partials of the initial state
+        if (needs_initial_refactor) {
+            TRY(refactor_now(s));
+        }
     } else {
         TRY(dev_alloc(s, &d.lu, (size_t)m * (size_t)m));
         TRY(dev_alloc(s, &d.lt, (size_t)m * (size_t)m));

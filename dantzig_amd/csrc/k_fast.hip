@@ -635,10 +635,11 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
                                                    const int *__restrict__ nonbasis,
                                                    const int *__restrict__ var_col, int *plist,
                                                    int *pslot, int col0, int col1,
-                                                   const long long *__restrict__ cptr)
+                                                   const long long *__restrict__ cptr, int *drow)
 {
     // single workgroup: the structural-position list must be built in position order
     for (int r = threadIdx.x; r < m; r += blockDim.x) dslot[r] = -1;
+    __syncthreads();
     __shared__ int s_count;
     if (threadIdx.x == 0) {
         int s = 0;
@@ -660,7 +661,19 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
                 nnz += cptr[code - col0 + 1] - cptr[code - col0];
             }
         ctl->nb_nnz = nnz;
-        ctl->ncompact = 0;
+        // dense columns of the inverse = rows whose slack is NOT basic.  None for the slack
+        // basis Simplex::new builds; a caller-supplied basis (warm start) has some, and the
+        // engine then builds Binv0 by a refactorisation before the first iteration.
+        int kd = 0;
+        for (int k = 0; k < q; ++k) {
+            const int code = var_col[nonbasis[k]];
+            if (code < 0) {
+                drow[kd] = -1 - code;
+                dslot[-1 - code] = kd;
+                ++kd;
+            }
+        }
+        ctl->ncompact = kd;
         ctl->neta = 0;
         ctl->nb_struct = s;
     }
@@ -866,7 +879,7 @@ void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
     hipMemsetAsync(d.Wc, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
     hipLaunchKernelGGL(k_fast_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.dslot, d.nonbasis,
-                       d.var_col, d.plist, d.pslot, d.col0, d.col1, d.csc ? d.cptr : nullptr);
+                       d.var_col, d.plist, d.pslot, d.col0, d.col1, d.csc ? d.cptr : nullptr, d.drow);
 }
 
 void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,

@@ -374,3 +374,29 @@ def test_unbounded_infeasible_and_degenerate_shapes(core, numerics):
     want = ora.simplex_solve(ora.stdform_from_dense(np.array([[2.0]]), np.array([4.0]), np.array([3.0])))
     assert res.status == want.status == "infeasible" and res.objective == want.objective == 6.0
     assert _log(res) == _log(want)
+
+
+def test_fast_warm_start_from_a_non_slack_basis(core):
+    """A caller-supplied basis with structural columns: FAST numerics factorises it on the
+    device first (blocked LU + MFMA) and then iterates; STRICT and the oracle start from the
+    same state, so all three must produce the same pivot log."""
+    a, b, c = core.gen_dense_lp(seed=81, m=60, n_struct=120)
+    first = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=25)
+    assert first.status == "iter_limit" and (first.basis < 120).sum() > 5
+    m, ns = 60, 120
+    full = np.concatenate([np.asarray(a), np.eye(m)], axis=1)
+    xb = np.linalg.solve(full[:, first.basis], b)            # x = B^-1 b for the new start
+    cc = np.concatenate([c, np.zeros(m)])
+    y = np.linalg.solve(full[:, first.basis].T, cc[first.basis])
+    zn = full[:, first.nonbasis].T @ y - cc[first.nonbasis]  # z = N^T B^-T c_B - c_N
+    cp, ri, val = ora.csc_from_dense(full)
+    sf = ora.StdForm(m=m, n=ns + m, col_ptr=cp, row_idx=ri, val=val, c=cc, constant=0.0,
+                     basis=first.basis.copy(), nonbasis=first.nonbasis.copy(), x=xb, z=zn)
+    want = ora.simplex_solve(sf)
+    lp = core.CoreLP(a=np.asarray(a), c=cc, basis=first.basis, nonbasis=first.nonbasis, x=xb, z=zn)
+    strict = core.solve(lp, numerics=core.STRICT)
+    fast = core.solve(lp, numerics=core.FAST, poll_interval=8)
+    assert strict.status == fast.status == want.status
+    assert _log(strict) == _log(want)
+    assert _log(fast) == _log(want)
+    assert abs(fast.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
