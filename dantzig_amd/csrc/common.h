@@ -223,4 +223,3 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
                          int *piv, int *spos, int *scode, int *lpos, int *lrow, int *singular,
                          hipStream_t st);
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
-void dzg_launch_shard_decide(const DzgDev &d, int mode, const double *xrecv, hipStream_t st);

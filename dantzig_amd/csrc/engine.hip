@@ -690,8 +690,7 @@ extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *s
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     const int pk = price_kernel_for(s);
-    dzg_launch_shard_decide(d, 0, recv_dev, st);           // merge + status()
-    dzg_launch_fast_select_prep(d, 2, 0, recv_dev, st);    // primal: FTRAN prep from the record
+    dzg_launch_fast_select_prep(d, 4, 0, recv_dev, st);    // merge + status() + primal FTRAN prep
     dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, recv_dev, st);
     dzg_launch_fast_btran(d, st);
     const bool prof = s->prof_slot >= 0 && (s->opts.profile & (1 << DZG_K_PRICE));
@@ -708,8 +707,7 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
     if (!s || !recv_dev || s->numerics != DZG_NUMERICS_FAST) return fail(DZG_E_ARG, "phase3");
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
-    dzg_launch_shard_decide(d, 1, recv_dev, st);           // merge: entering position / z values
-    dzg_launch_fast_select_prep(d, 3, 0, recv_dev, st);    // dual: FTRAN prep from the record
+    dzg_launch_fast_select_prep(d, 5, 0, recv_dev, st);    // merge + (dual) FTRAN prep
     dzg_launch_fast_gemv(d, DZG_STEP_DUAL, recv_dev, st);
     dzg_launch_fast_pivot(d, st);
     dzg_launch_fast_update(d, 0, st);

@@ -64,6 +64,26 @@ __device__ __forceinline__ double block_sum(double x)
     return t;
 }
 
+__device__ __forceinline__ int shard_merge(const double *__restrict__ xrecv, long long xstride,
+                                           int world, DzgCand &win)
+{
+    int w = -1;
+    win.r = 0.0;
+    win.k = -1;
+    for (int r = 0; r < world; ++r) {
+        const double *rec = xrecv + (long long)r * xstride;
+        DzgCand c;
+        c.r = rec[0];
+        c.k = (int)rec[1];
+        if (c.k < 0 || c.r != c.r) continue;
+        if (win.k < 0 || c.r > win.r || (c.r == win.r && c.k < win.k)) {
+            win = c;
+            w = r;
+        }
+    }
+    return w;
+}
+
 // ---------------------------------------------------------------------------------
 // k_fast_select_prep<MODE>
 //   MODE 0: head of the iteration.  status(): first pivots on both sides from the partials
@@ -84,13 +104,22 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
     const double *__restrict__ fpz_r, const int *__restrict__ fpz_k,
     const double *__restrict__ rz_r, const int *__restrict__ rz_k, int nrz,
     const double *__restrict__ W, long long ldw, const int *__restrict__ drow,
-    double *__restrict__ ag, double *__restrict__ beta, double eps)
+    double *__restrict__ ag, double *__restrict__ beta, double eps, int world)
 {
-    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
     int epos;
-    if (MODE == 0) {
-        const DzgCand cj = reduce_partials(fpz_r, fpz_k, DZG_NB_UPD);
+    int code_known = 0, code_val = -1;
+    if (MODE == 0 || MODE == 4) {
+        // MODE 0: z-side first pivot from this GPU's partials.  MODE 4 (column sharding): from the
+        // merge of every rank's proposal -- all ranks see the same records in the same order and
+        // apply the same rule, so they take the same decision without a broadcast.
+        DzgCand cj;
+        int w = -1;
+        if (MODE == 4)
+            w = shard_merge(xrecv, xstride, world, cj);
+        else
+            cj = reduce_partials(fpz_r, fpz_k, DZG_NB_UPD);
         const DzgCand ci = reduce_partials(fpx_r, fpx_k, DZG_NB_UPD);
         const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
         int kind;
@@ -131,12 +160,63 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
             ctl->mu = mu;
             ctl->enter_pos = kind == DZG_STEP_PRIMAL ? cj.k : -1;
             ctl->leave_pos = kind == DZG_STEP_DUAL ? ci.k : -1;
+            if (MODE == 4) ctl->use_record = 0;
         }
         if (kind != DZG_STEP_PRIMAL) return;
         epos = cj.k;
-    } else if (MODE == 2) { // sharded: k_shard_decide already published the selection
+        if (MODE == 4) { // the entering column travels in the winner's record
+            code_known = 1;
+            code_val = (int)xrecv[(long long)w * xstride + 5];
+            c.enter_src = w;
+            if (lead) ctl->enter_src = w;
+        }
+    } else if (MODE == 2) { // selection already published in the control block
         if (c.kind != need_kind) return;
         epos = c.enter_pos;
+        code_known = 1;
+        code_val = c.enter_code;
+    } else if (MODE == 5) {
+        // column sharding, second exchange.  Dual step: merge the ratio-test proposals (none =
+        // Infeasible, src/simplex.rs:325), take the entering column and z, zbar, dz from the
+        // winner's record.  Primal step: only z, zbar, dz of the entering position are needed.
+        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+        if (c.kind == DZG_STEP_DUAL) {
+            DzgCand cw;
+            const int w = shard_merge(xrecv, xstride, world, cw);
+            if (w < 0) {
+                if (lead) ctl->status = DZG_INFEASIBLE;
+                return;
+            }
+            const double *rec = xrecv + (long long)w * xstride;
+            epos = cw.k;
+            code_known = 1;
+            code_val = (int)rec[5];
+            c.enter_src = w;
+            if (lead) {
+                ctl->enter_pos = epos;
+                ctl->enter_src = w;
+                ctl->zr = rec[2];
+                ctl->zbar_r = rec[3];
+                ctl->dz_r = rec[4];
+                ctl->use_record = 1;
+            }
+        } else {
+            if (lead) {
+                int w = -1;
+                for (int r = 0; r < world && w < 0; ++r)
+                    if ((int)xrecv[(long long)r * xstride + 1] == c.enter_pos) w = r;
+                if (w < 0) {
+                    ctl->status = DZG_PANIC; // no rank owns the entering position: cannot happen
+                } else {
+                    const double *rec = xrecv + (long long)w * xstride;
+                    ctl->zr = rec[2];
+                    ctl->zbar_r = rec[3];
+                    ctl->dz_r = rec[4];
+                    ctl->use_record = 1;
+                }
+            }
+            return; // FTRAN already happened in phase 2
+        }
     } else {
         if (c.kind != DZG_STEP_DUAL) return;
         const DzgCand c = reduce_partials(rz_r, rz_k, nrz);
@@ -148,7 +228,7 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_pos = epos;
     }
     // ---- FTRAN preparation for the entering variable
-    const int code = MODE == 2 ? c.enter_code : var_col[nonbasis[epos]];
+    const int code = code_known ? code_val : var_col[nonbasis[epos]];
     if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
     const double *a = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
     const int neta = c.neta, k = c.ncompact;
@@ -686,26 +766,6 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
 // The merges below are deterministic (largest ratio, lowest GLOBAL position) and every rank
 // sees the same records in the same order, so all ranks take identical decisions.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ int shard_merge(const double *__restrict__ xrecv, long long xstride,
-                                           int world, DzgCand &win)
-{
-    int w = -1;
-    win.r = 0.0;
-    win.k = -1;
-    for (int r = 0; r < world; ++r) {
-        const double *rec = xrecv + (long long)r * xstride;
-        DzgCand c;
-        c.r = rec[0];
-        c.k = (int)rec[1];
-        if (c.k < 0 || c.r != c.r) continue;
-        if (win.k < 0 || c.r > win.r || (c.r == win.r && c.k < win.k)) {
-            win = c;
-            w = r;
-        }
-    }
-    return w;
-}
-
 // MODE 0: propose the first-pivot candidate of the z side (before status()).
 // MODE 1: after pricing -- dual: propose the ratio-test candidate; primal: the owner of the
 //         entering position publishes its z, zbar, dz.
@@ -771,103 +831,6 @@ __global__ __launch_bounds__(256) void k_shard_scatter_col(const DzgCtl *ctl, in
     }
 }
 
-// MODE 0: merge the proposals, then status() exactly as k_fast_select_prep<0>.
-// MODE 1: merge the second exchange: dual -> entering position (none = Infeasible), its
-//         column and z, zbar, dz; primal -> z, zbar, dz of the entering position.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_shard_decide(DzgCtl *ctl, int m, int world,
-                                                      const double *__restrict__ xrecv,
-                                                      long long xstride,
-                                                      const double *__restrict__ fpx_r,
-                                                      const int *__restrict__ fpx_k, double eps)
-{
-    if (ctl->status != DZG_RUNNING) return;
-    const bool lead = threadIdx.x == 0;
-    if (MODE == 0) {
-        DzgCand cj;
-        const int w = shard_merge(xrecv, xstride, world, cj);
-        const DzgCand ci = reduce_partials(fpx_r, fpx_k, DZG_NB_UPD);
-        if (!lead) return;
-        int kind;
-        double mu;
-        if (cj.k >= 0 && ci.k >= 0) {
-            const double primal = ci.r, dual = cj.r;
-            if (primal <= eps && dual <= eps) {
-                ctl->status = DZG_OPTIMAL;
-                return;
-            }
-            if (primal < dual) {
-                kind = DZG_STEP_PRIMAL;
-                mu = dual;
-            } else {
-                kind = DZG_STEP_DUAL;
-                mu = primal;
-            }
-        } else if (cj.k >= 0) {
-            kind = DZG_STEP_PRIMAL;
-            mu = cj.r;
-        } else if (ci.k >= 0) {
-            kind = DZG_STEP_DUAL;
-            mu = ci.r;
-        } else {
-            ctl->status = DZG_PANIC;
-            return;
-        }
-        if (ctl->iter >= ctl->iter_stop) {
-            ctl->status = DZG_ITER_LIMIT;
-            return;
-        }
-        if (m == 0) {
-            ctl->status = DZG_PANIC;
-            return;
-        }
-        ctl->kind = kind;
-        ctl->mu = mu;
-        ctl->use_record = 0;
-        if (kind == DZG_STEP_PRIMAL) {
-            ctl->enter_pos = cj.k;
-            ctl->leave_pos = -1;
-            ctl->enter_code = (int)xrecv[(long long)w * xstride + 5];
-            ctl->enter_src = w;
-        } else {
-            ctl->leave_pos = ci.k;
-            ctl->enter_pos = -1;
-        }
-    } else {
-        if (!lead) return;
-        if (ctl->kind == DZG_STEP_DUAL) {
-            DzgCand c;
-            const int w = shard_merge(xrecv, xstride, world, c);
-            if (w < 0) {
-                ctl->status = DZG_INFEASIBLE; // src/simplex.rs:325
-                return;
-            }
-            const double *rec = xrecv + (long long)w * xstride;
-            ctl->enter_pos = c.k;
-            ctl->enter_code = (int)rec[5];
-            ctl->enter_src = w;
-            ctl->zr = rec[2];
-            ctl->zbar_r = rec[3];
-            ctl->dz_r = rec[4];
-            ctl->use_record = 1;
-        } else {
-            const int want = ctl->enter_pos;
-            int w = -1;
-            for (int r = 0; r < world && w < 0; ++r)
-                if ((int)xrecv[(long long)r * xstride + 1] == want) w = r;
-            if (w < 0) {
-                ctl->status = DZG_PANIC; // no rank owns the entering position: cannot happen
-                return;
-            }
-            const double *rec = xrecv + (long long)w * xstride;
-            ctl->zr = rec[2];
-            ctl->zbar_r = rec[3];
-            ctl->dz_r = rec[4];
-            ctl->use_record = 1;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------
@@ -885,17 +848,21 @@ void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
 void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,
                                  hipStream_t st)
 {
-    // mode 0: status + primal prep, 1: dual ratio + prep, 2/3: sharded prep of a primal/dual step
+    // mode 0: status + primal prep          1: dual ratio test + prep          (one GPU)
+    //      2/3: prep only, selection already in the control block
+    //      4: merge proposals + status + primal prep     5: merge second exchange + dual prep
 #define SEL_ARGS(need) d.ctl, d.m, d.A, d.lda, d.col0, xrecv, d.xstride, need, d.nonbasis, d.var_col,    \
                        d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.rz_r, d.rz_k, nrz, d.W, d.ldw, d.drow, d.ag,  \
-                       d.beta, d.eps
-    if (mode == 0)
-        hipLaunchKernelGGL((k_fast_select_prep<0>), dim3(R_ + 1), dim3(256), 0, st, SEL_ARGS(0));
-    else if (mode == 1)
-        hipLaunchKernelGGL((k_fast_select_prep<1>), dim3(R_ + 1), dim3(256), 0, st, SEL_ARGS(0));
-    else
-        hipLaunchKernelGGL((k_fast_select_prep<2>), dim3(R_ + 1), dim3(256), 0, st,
-                           SEL_ARGS(mode == 2 ? DZG_STEP_PRIMAL : DZG_STEP_DUAL));
+                       d.beta, d.eps, d.world
+    const dim3 grid(R_ + 1), block(256);
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((k_fast_select_prep<0>), grid, block, 0, st, SEL_ARGS(0)); break;
+    case 1: hipLaunchKernelGGL((k_fast_select_prep<1>), grid, block, 0, st, SEL_ARGS(0)); break;
+    case 2: hipLaunchKernelGGL((k_fast_select_prep<2>), grid, block, 0, st, SEL_ARGS(DZG_STEP_PRIMAL)); break;
+    case 3: hipLaunchKernelGGL((k_fast_select_prep<2>), grid, block, 0, st, SEL_ARGS(DZG_STEP_DUAL)); break;
+    case 4: hipLaunchKernelGGL((k_fast_select_prep<4>), grid, block, 0, st, SEL_ARGS(0)); break;
+    default: hipLaunchKernelGGL((k_fast_select_prep<5>), grid, block, 0, st, SEL_ARGS(0)); break;
+    }
 #undef SEL_ARGS
 }
 
@@ -954,14 +921,4 @@ void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend,
     if (d.csc)
         hipLaunchKernelGGL(k_shard_scatter_col, dim3(1), dim3(256), 0, st, d.ctl, mode, d.cptr,
                            d.ridx, d.cval, d.col0, d.col1, xsend);
-}
-
-void dzg_launch_shard_decide(const DzgDev &d, int mode, const double *xrecv, hipStream_t st)
-{
-    if (mode == 0)
-        hipLaunchKernelGGL((k_shard_decide<0>), dim3(1), dim3(256), 0, st, d.ctl, d.m, d.world,
-                           xrecv, d.xstride, d.fpx_r, d.fpx_k, d.eps);
-    else
-        hipLaunchKernelGGL((k_shard_decide<1>), dim3(1), dim3(256), 0, st, d.ctl, d.m, d.world,
-                           xrecv, d.xstride, d.fpx_r, d.fpx_k, d.eps);
 }
