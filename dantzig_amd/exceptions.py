@@ -1,9 +1,14 @@
-"""Solver outcome exceptions (same names and meaning as dantzig.exceptions)."""
+"""Exceptions raised by `.solve()` -- the two outcomes of the reference's `Error` enum
+(src/error.rs:3-7), under the names the reference's Python package uses."""
 
 
-class UnboundedError(Exception):
-    """The objective can be improved without limit."""
+class SolveError(Exception):
+    """A solve ended without an optimal vertex."""
 
 
-class InfeasibleError(Exception):
-    """No point satisfies all constraints."""
+class UnboundedError(SolveError):
+    """The objective can be improved without limit (src/simplex.rs:313)."""
+
+
+class InfeasibleError(SolveError):
+    """No point satisfies all constraints (src/simplex.rs:325)."""

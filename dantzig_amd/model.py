@@ -1,53 +1,114 @@
 """Modelling layer: Variable, LinExpr, AffExpr, Constraint.
 
-Same public surface and lowering rules as the reference's python-source/dantzig/model.py
-(cited per method), written against dantzig_amd.rust:
+The public surface and the lowering rules are those of the reference's modelling module
+(python-source/dantzig/model.py, cited per rule below); the implementation is this project's
+own: all arithmetic and all comparisons of the three expression kinds live in one mixin that
+works on a normal form "(linear part, constant or None)".
 
-  * Variable + number / AffExpr -> AffExpr;  Variable + Variable / LinExpr -> LinExpr
-  * every comparison is taken on  lhs - rhs  as an AffExpr:  linexpr (op) -constant
-  * `==` lowers to two opposite inequalities, `>=` to one negated `<=`   (model.py:323-375)
-  * Constraint objects are truthy, so a chained  a <= x <= b  keeps only  x <= b
-    (Python evaluates `(a <= x) and (x <= b)`), exactly like the reference
-    (tests/test_optimize.py:67).
+Rules kept from the reference
+  * a result is a LinExpr while no constant has been involved, an AffExpr afterwards
+    (Variable + Variable -> LinExpr, Variable + 1 -> AffExpr; model.py:113-150,199-224);
+  * a purely linear operand counts as constant 0.0 when it meets an affine one, so the float
+    operations are the reference's (`0.0 + 3`, `0.0 - 3`, ...; model.py:186-187,279-313);
+  * every comparison is taken on `lhs - rhs`:  linear part (op) -constant  (model.py:323-347);
+  * `==` lowers to two opposite inequalities, `>=` to one negated `<=` (model.py:350-375);
+  * Constraint objects are truthy, so a chained  a <= x <= b  keeps only  x <= b  -- Python
+    evaluates `(a <= x) and (x <= b)` -- exactly like the reference (tests/test_optimize.py:67).
 """
 from __future__ import annotations
 
-from typing import Union
+from typing import Optional, Tuple, Union
 
 from . import rust as rs
 
 Number = Union[int, float]
+Operand = Union[Number, "Variable", "LinExpr", "AffExpr"]
 
 
-def _is_number(v) -> bool:
-    return isinstance(v, (int, float))
+def _is_number(value) -> bool:
+    return isinstance(value, (int, float))
+
+
+def _build(linear: rs.PyLinExpr, constant: Optional[float]):
+    """Normal form -> LinExpr (no constant involved so far) or AffExpr."""
+    expr = LinExpr(linexpr=linear)
+    return expr if constant is None else AffExpr(linexpr=expr, constant=constant)
 
 
 class _Algebra:
-    """Operators shared by Variable, LinExpr and AffExpr.  Subclasses provide to_affexpr()
-    and, when they are purely linear, to_linexpr()."""
+    """+, -, *, unary -, ==, <=, >= for Variable, LinExpr and AffExpr."""
 
-    def to_affexpr(self) -> "AffExpr":
+    def _normal_form(self) -> Tuple[rs.PyLinExpr, Optional[float]]:
         raise NotImplementedError
 
-    # ---- comparisons build constraints (model.py:152-165, 226-239, 323-347)
-    def __eq__(self, rhs) -> "Constraint":  # type: ignore[override]
-        diff = self.to_affexpr() - rhs
-        return Constraint.equality(linexpr=diff.linexpr, b=-diff.constant)
+    # ---------------------------------------------------------------- conversions
+    def to_linexpr(self) -> "LinExpr":
+        linear, constant = self._normal_form()
+        if constant is not None:
+            raise TypeError("an affine expression has no purely linear form")
+        return LinExpr(linexpr=linear)
 
-    def __le__(self, rhs) -> "Constraint":
-        diff = self.to_affexpr() - rhs
-        return Constraint.less_than_eq(linexpr=diff.linexpr, b=-diff.constant)
+    def to_affexpr(self) -> "AffExpr":
+        linear, constant = self._normal_form()
+        return AffExpr(linexpr=LinExpr(linexpr=linear), constant=0.0 if constant is None else constant)
 
-    def __ge__(self, rhs) -> "Constraint":
-        diff = self.to_affexpr() - rhs
-        return Constraint.greater_than_eq(linexpr=diff.linexpr, b=-diff.constant)
+    # ---------------------------------------------------------------- arithmetic
+    def _combine(self, other: Operand, sign: int, what: str):
+        linear, constant = self._normal_form()
+        if _is_number(other):
+            base = 0.0 if constant is None else constant
+            return _build(linear, base + other if sign > 0 else base - other)
+        if not isinstance(other, _Algebra):
+            raise TypeError(f"{type(self).__name__}.{what}() does not support {type(other)}")
+        other_linear, other_constant = other._normal_form()
+        merged = linear + (other_linear if sign > 0 else -other_linear)
+        if constant is None and other_constant is None:
+            return _build(merged, None)
+        mine = 0.0 if constant is None else constant
+        theirs = 0.0 if other_constant is None else other_constant
+        return _build(merged, mine + theirs if sign > 0 else mine - theirs)
+
+    def __add__(self, rhs: Operand):
+        return self._combine(rhs, +1, "__add__")
+
+    def __sub__(self, rhs: Operand):
+        return self._combine(rhs, -1, "__sub__")
 
     def __radd__(self, lhs: Number) -> "AffExpr":
         return self + lhs
 
+    def __rsub__(self, lhs: Number) -> "AffExpr":
+        return (-self) + lhs
+
+    def __neg__(self):
+        linear, constant = self._normal_form()
+        return _build(-linear, None if constant is None else -constant)
+
+    def __mul__(self, rhs: Number):
+        if not _is_number(rhs):
+            raise TypeError(f"{type(self).__name__}.__mul__() only supports int and float")
+        linear, constant = self._normal_form()
+        return _build(linear * rhs, None if constant is None else rhs * constant)
+
     def __rmul__(self, lhs: Number):
         return self * lhs
+
+    # ---------------------------------------------------------------- comparisons -> constraints
+    def _difference(self, rhs: Operand) -> Tuple["LinExpr", float]:
+        diff = self.to_affexpr() - rhs
+        return diff.linexpr, -diff.constant
+
+    def __eq__(self, rhs: Operand) -> "Constraint":  # type: ignore[override]
+        linexpr, b = self._difference(rhs)
+        return Constraint.equality(linexpr=linexpr, b=b)
+
+    def __le__(self, rhs: Operand) -> "Constraint":
+        linexpr, b = self._difference(rhs)
+        return Constraint.less_than_eq(linexpr=linexpr, b=b)
+
+    def __ge__(self, rhs: Operand) -> "Constraint":
+        linexpr, b = self._difference(rhs)
+        return Constraint.greater_than_eq(linexpr=linexpr, b=b)
 
 
 class Variable(_Algebra):
@@ -82,28 +143,8 @@ class Variable(_Algebra):
     def to_rust_variable(self) -> rs.Variable:
         return self._variable
 
-    def to_linexpr(self) -> "LinExpr":
-        return LinExpr.from_rust_variable(self._variable)
-
-    def to_affexpr(self) -> "AffExpr":
-        return AffExpr.from_rust_variable(self._variable)
-
-    def __add__(self, rhs):
-        return self.to_linexpr() + rhs
-
-    def __sub__(self, rhs):
-        return self.to_linexpr() - rhs
-
-    def __rsub__(self, lhs: Number) -> "AffExpr":
-        return -self.to_linexpr() + lhs
-
-    def __mul__(self, rhs: Number) -> "LinExpr":
-        if not _is_number(rhs):
-            raise TypeError("Variable.__mul__() only supports int and float")
-        return self.to_linexpr() * rhs
-
-    def __neg__(self) -> "LinExpr":
-        return -self.to_linexpr()
+    def _normal_form(self):
+        return rs.PyLinExpr(coefs=[1.0], vars=[self._variable]), None
 
     def __hash__(self) -> int:
         return hash(self.id)
@@ -114,6 +155,8 @@ class Variable(_Algebra):
 
 class LinExpr(_Algebra):
     """A linear combination of variables (model.py:171-243)."""
+
+    __hash__ = None  # type: ignore[assignment]
 
     def __init__(self, *, linexpr: rs.PyLinExpr) -> None:
         self._linexpr = linexpr
@@ -128,42 +171,17 @@ class LinExpr(_Algebra):
     def to_linexpr(self) -> "LinExpr":
         return self
 
-    def to_affexpr(self) -> "AffExpr":
-        return AffExpr(linexpr=self, constant=0.0)
-
     def map_ids_to_coefs(self) -> dict:
         return self._linexpr.map_ids_to_coefs()
 
-    def __add__(self, rhs):
-        if _is_number(rhs) or isinstance(rhs, AffExpr):
-            return self.to_affexpr() + rhs
-        if isinstance(rhs, (Variable, LinExpr)):
-            return LinExpr(linexpr=self._linexpr + rhs.to_linexpr()._linexpr)
-        raise TypeError(f"LinExpr.__add__() does not support {type(rhs)}")
-
-    def __sub__(self, rhs):
-        if _is_number(rhs) or isinstance(rhs, AffExpr):
-            return self.to_affexpr() - rhs
-        if isinstance(rhs, (Variable, LinExpr)):
-            return self + (-rhs.to_linexpr())
-        raise TypeError(f"LinExpr.__sub__() does not support {type(rhs)}")
-
-    def __rsub__(self, lhs: Number) -> "AffExpr":
-        return -self + lhs
-
-    def __mul__(self, rhs: Number) -> "LinExpr":
-        if not _is_number(rhs):
-            raise TypeError("LinExpr.__mul__() only supports int and float")
-        return LinExpr(linexpr=self._linexpr * rhs)
-
-    def __neg__(self) -> "LinExpr":
-        return LinExpr(linexpr=-self._linexpr)
-
-    __hash__ = None  # type: ignore[assignment]
+    def _normal_form(self):
+        return self._linexpr, None
 
 
 class AffExpr(_Algebra):
-    """linear part + constant (model.py:246-347)."""
+    """Linear part plus constant (model.py:246-347)."""
+
+    __hash__ = None  # type: ignore[assignment]
 
     def __init__(self, *, linexpr: LinExpr, constant: Number) -> None:
         self._affexpr = rs.PyAffExpr(linexpr=linexpr.to_rust_linexpr(), constant=constant)
@@ -178,66 +196,36 @@ class AffExpr(_Algebra):
     def to_affexpr(self) -> "AffExpr":
         return self
 
-    @property
-    def linexpr(self) -> LinExpr:
-        return LinExpr(linexpr=self._affexpr.pylinexpr)
+    linexpr = property(lambda self: LinExpr(linexpr=self._affexpr.pylinexpr))
+    constant = property(lambda self: self._affexpr.constant)
 
-    @property
-    def constant(self) -> float:
-        return self._affexpr.constant
-
-    def __add__(self, rhs) -> "AffExpr":
-        if _is_number(rhs):
-            return AffExpr(linexpr=self.linexpr, constant=self.constant + rhs)
-        if isinstance(rhs, (Variable, LinExpr, AffExpr)):
-            other = rhs.to_affexpr()
-            return AffExpr(linexpr=self.linexpr + other.linexpr,
-                           constant=self.constant + other.constant)
-        raise TypeError(f"AffExpr.__add__() does not support {type(rhs)}")
-
-    def __sub__(self, rhs) -> "AffExpr":
-        if _is_number(rhs):
-            return AffExpr(linexpr=self.linexpr, constant=self.constant - rhs)
-        if isinstance(rhs, (Variable, LinExpr, AffExpr)):
-            other = rhs.to_affexpr()
-            return AffExpr(linexpr=self.linexpr - other.linexpr,
-                           constant=self.constant - other.constant)
-        raise TypeError(f"AffExpr.__sub__() does not support {type(rhs)}")
-
-    def __rsub__(self, lhs: Number) -> "AffExpr":
-        return -self + lhs
-
-    def __mul__(self, rhs: Number) -> "AffExpr":
-        if not _is_number(rhs):
-            raise TypeError("AffExpr.__mul__() only supports int and float")
-        return AffExpr(linexpr=rhs * self.linexpr, constant=rhs * self.constant)
-
-    def __neg__(self) -> "AffExpr":
-        return AffExpr(linexpr=-self.linexpr, constant=-self.constant)
-
-    __hash__ = None  # type: ignore[assignment]
+    def _normal_form(self):
+        return self._affexpr.pylinexpr, self._affexpr.constant
 
 
 class Constraint:
-    """One or two `linexpr <= b` rows (model.py:350-378)."""
+    """One or two rows `linexpr <= b` (model.py:350-378)."""
 
     def __init__(self, *, inequalities: list) -> None:
         self._inequalities = inequalities
 
+    @staticmethod
+    def _row(linexpr: LinExpr, b: Number, negate: bool) -> rs.PyInequality:
+        if negate:
+            return rs.PyInequality(linexpr=(-linexpr).to_rust_linexpr(), b=-b)
+        return rs.PyInequality(linexpr=linexpr.to_rust_linexpr(), b=b)
+
     @classmethod
     def less_than_eq(cls, *, linexpr: LinExpr, b: Number) -> "Constraint":
-        return cls(inequalities=[rs.PyInequality(linexpr=linexpr.to_rust_linexpr(), b=b)])
+        return cls(inequalities=[cls._row(linexpr, b, False)])
 
     @classmethod
     def greater_than_eq(cls, *, linexpr: LinExpr, b: Number) -> "Constraint":
-        return cls(inequalities=[rs.PyInequality(linexpr=(-linexpr).to_rust_linexpr(), b=-b)])
+        return cls(inequalities=[cls._row(linexpr, b, True)])
 
     @classmethod
     def equality(cls, *, linexpr: LinExpr, b: Number) -> "Constraint":
-        return cls(inequalities=[
-            rs.PyInequality(linexpr=linexpr.to_rust_linexpr(), b=b),
-            rs.PyInequality(linexpr=(-linexpr).to_rust_linexpr(), b=-b),
-        ])
+        return cls(inequalities=[cls._row(linexpr, b, False), cls._row(linexpr, b, True)])
 
     def rust_inequalities(self) -> list:
         return self._inequalities
