@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -92,6 +93,9 @@ struct dzg_solver {
     int *rf_piv = nullptr, *rf_spos = nullptr, *rf_scode = nullptr, *rf_lpos = nullptr,
         *rf_lrow = nullptr, *rf_counts = nullptr;
     long long since_refactor = 0;
+    // STRICT: the O(m) launches of one basis solve, captured once and replayed (hipGraph)
+    hipGraphExec_t g_solve[2] = {nullptr, nullptr}; // [0] B dx = a_j, [1] B^T v = e_p
+    bool graphs_tried = false;
     int prof_slot = -1; // phase path: event slot of the iteration being enqueued (-1: none)
     int64_t refactors = 0;
     // column sharding
@@ -201,6 +205,8 @@ extern "C" void dzg_solver_destroy(dzg_solver *s)
 {
     if (!s) return;
     shard_comm_destroy(s);
+    for (hipGraphExec_t g : s->g_solve)
+        if (g) hipGraphExecDestroy(g);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     for (void *p : s->allocs) hipFree(p);
     if (s->h_ctl) hipHostFree(s->h_ctl);
@@ -606,6 +612,36 @@ static int run_fast(dzg_solver *s)
     return 0;
 }
 
+// STRICT basis solve = gather + 2(m-1) elimination launches + one substitution launch, the same
+// sequence with the same arguments every time (the kernels read the basis and the control
+// block from memory): capture it once per orientation and replay it, so an iteration costs two
+// graph launches instead of ~4m kernel launches on the host.
+static void strict_solve(dzg_solver *s, int transposed)
+{
+    const DzgDev &d = s->d;
+    hipStream_t st = s->st;
+    if (!s->graphs_tried) {
+        s->graphs_tried = true;
+        const bool off = getenv("DZG_NO_GRAPH") != nullptr; // diagnostic switch
+        for (int t = 0; t < 2 && !off; ++t) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) break;
+            dzg_launch_strict_solve(d, t, st);
+            if (hipStreamEndCapture(st, &graph) != hipSuccess || !graph) {
+                (void)hipGetLastError();
+                break;
+            }
+            if (hipGraphInstantiate(&s->g_solve[t], graph, nullptr, nullptr, 0) != hipSuccess) {
+                s->g_solve[t] = nullptr;
+                (void)hipGetLastError();
+            }
+            hipGraphDestroy(graph);
+        }
+    }
+    if (s->g_solve[transposed] && hipGraphLaunch(s->g_solve[transposed], st) == hipSuccess) return;
+    dzg_launch_strict_solve(d, transposed, st); // capture unavailable: plain launches
+}
+
 static int run_strict(dzg_solver *s)
 {
     const DzgDev &d = s->d;
@@ -617,19 +653,19 @@ static int run_strict(dzg_solver *s)
         if (s->h_ctl->kind == DZG_STEP_PRIMAL) { // src/simplex.rs:308-318
             dzg_launch_load_column(d, -1, st);
             hipMemcpyAsync(d.dx, d.acol, sizeof(double) * (size_t)d.m, hipMemcpyDeviceToDevice, st);
-            dzg_launch_strict_solve(d, 0, st);
+            strict_solve(s, 0);
             dzg_launch_ratio(d, DZG_STEP_PRIMAL, st);
             dzg_launch_unit_rhs(d, st); // needs leave_pos: no-op if the ratio test found none
-            dzg_launch_strict_solve(d, 1, st);
+            strict_solve(s, 1);
             dzg_launch_price(d, DZG_PRICE_SEQ, st);
         } else { // :320-330
             dzg_launch_unit_rhs(d, st);
-            dzg_launch_strict_solve(d, 1, st);
+            strict_solve(s, 1);
             dzg_launch_price(d, DZG_PRICE_SEQ, st);
             dzg_launch_ratio(d, DZG_STEP_DUAL, st);
             dzg_launch_load_column(d, -1, st);
             hipMemcpyAsync(d.dx, d.acol, sizeof(double) * (size_t)d.m, hipMemcpyDeviceToDevice, st);
-            dzg_launch_strict_solve(d, 0, st);
+            strict_solve(s, 0);
         }
         dzg_launch_prepare(d, st);
         dzg_launch_update_vectors(d, st);
