@@ -86,3 +86,22 @@ def test_first_pivots_match_reference_arithmetic(core, lp_data):
     fast = core.solve(lp, numerics=core.FAST, max_iter=3)
     assert [(k, e, l) for k, e, l, _ in fast.pivots] == [(k, e, l) for k, e, l, _ in strict.pivots]
     assert np.allclose([p[3] for p in fast.pivots], [p[3] for p in strict.pivots], rtol=1e-12)
+
+
+def test_whole_solve_is_certified_optimal_by_lapack(core):
+    """4096 x 8192 to optimality (about 180 000 pivots), then strong duality on the host: the
+    final basis alone must be primal and dual feasible under LAPACK's arithmetic and the engine's
+    objective must agree to the north star's 1e-9.  (8192 x 16384: tools/full_solve.py,
+    profiles/r01_full_solve_8192x16384.txt -- 514 893 pivots, gap 7e-13.)"""
+    from tests.optimality import certificate
+
+    a, b, c = core.gen_dense_lp(seed=1006, m=4096, n_struct=8192)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    res = core.solve(lp, log=False, numerics=core.FAST, poll_interval=256)
+    assert res.status == "optimal"
+    assert res.max_pivot_error < 1e-9
+    cert = certificate(np.asarray(a), b, c, res.basis)
+    scale = max(1.0, abs(cert["primal_obj"]))
+    assert cert["primal_infeas"] <= 1e-9 and cert["dual_infeas"] <= 1e-9
+    assert abs(cert["primal_obj"] - cert["dual_obj"]) <= 1e-9 * scale
+    assert abs(res.objective - cert["primal_obj"]) <= 1e-9 * scale
