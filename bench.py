@@ -8,7 +8,10 @@ fp64 LP (generator G1, seed 1003).  One "step" = one executed pivot
 between barriers, continuing the same solve trajectory.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--rows M --cols NS --seed S]
-                  [--price seq|wave] [--no-cpu-baseline]
+                  [--price seq|wave] [--no-cpu-baseline] [--no-pmc-traffic] [--no-secondary]
+
+The default invocation also measures config 5 (32768 x 65536, the LP the multi-GPU target is quoted
+on) and reports it under "secondary"; `value` is always the 8192 x 16384 LP.
 
 Prints ONE JSON line on rank 0.
 """
@@ -77,7 +80,7 @@ def pmc_traffic(args) -> dict | None:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "20",
                    "--rows", str(args.rows), "--cols", str(args.cols), "--seed", str(args.seed),
-                   "--price", args.price, "--no-cpu-baseline", "--no-pmc-traffic"]
+                   "--price", args.price, "--no-cpu-baseline", "--no-pmc-traffic", "--no-secondary"]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=240, check=True)
@@ -101,6 +104,93 @@ def pmc_traffic(args) -> dict | None:
             "note": "rocprofv3 --pmc, separate passes; FETCH_SIZE x2 (gfx950), KiB units"}
 
 
+SECONDARY = {"rows": 32768, "cols": 65536, "seed": 1005, "steps": 300, "warmup": 50}
+
+
+def secondary_wanted(args) -> bool:
+    """The config-5 measurement rides along with the default invocation only."""
+    return (not args.no_secondary and args.rows == 8192 and args.cols == 16384
+            and args.sparse_per_col == 0 and args.numerics == "fast")
+
+
+def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, warmup) -> dict:
+    """One workload on one GPU: generate, upload (untimed), `warmup` pivots, then `steps` timed."""
+    from dantzig_amd import _ffi, core
+
+    t_gen = time.perf_counter()
+    if sparse_per_col > 0:
+        cp, ri, val, b, c = core.gen_sparse_lp(seed, rows, cols, sparse_per_col)
+        lp = core.CoreLP.from_csc(rows, cp, ri, val, b, c)
+    else:
+        a, b, c = core.gen_dense_lp(seed=seed, m=rows, n_struct=cols)
+        lp = core.CoreLP.from_inequality_form(a, b, c)
+    t_gen = time.perf_counter() - t_gen
+    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[price_name]
+    numerics = core.FAST if numerics_name == "fast" else core.STRICT
+    t_up = time.perf_counter()
+    solver = core.Solver(lp, numerics=numerics, price_kernel=price,
+                         profile=1 << _ffi.K_PRICE, poll_interval=50)
+    t_up = time.perf_counter() - t_up
+    try:
+        status = solver.run(warmup) if warmup > 0 else "iter_limit"
+        r0 = solver.result(log=False)
+        t0 = time.perf_counter()
+        if status == "iter_limit":
+            status = solver.run(steps)
+        t1 = time.perf_counter()
+        r1 = solver.result(log=False)
+    finally:
+        solver.close()
+
+    steps_done = r1.iterations - r0.iterations
+    elapsed = t1 - t0
+    price_ms = r1.kernel_ms["price"] - r0.kernel_ms["price"]
+    price_launches = r1.kernel_launches["price"] - r0.kernel_launches["price"]
+    price_bytes = r1.price_bytes - r0.price_bytes
+    achieved = (price_bytes / 1e9) / (price_ms / 1e3) if price_ms > 0 else float("nan")
+    return {
+        "metric": "simplex_iterations_per_sec",
+        "value": steps_done / elapsed if elapsed > 0 else float("nan"),
+        "unit": "iterations/s",
+        "n_gpus": 1,
+        "steps": steps_done,
+        "warmup": r0.iterations,
+        "ms_per_step": 1e3 * elapsed / max(steps_done, 1),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"dense random LP {rows}x{cols} fp64, generator G1 seed {seed}"
+                         if sparse_per_col <= 0 else
+                         f"sparse random LP {rows}x{cols} fp64, {sparse_per_col} "
+                         f"nonzeros per column (CSC), generator G2 seed {seed}"),
+            "numerics": r1.numerics,
+            "price_kernel": price_name,
+            "status_after_timed_region": status,
+            "requested_steps": steps,
+            "lp_generation_s": round(t_gen, 3),
+            "upload_s": round(t_up, 3),
+            "max_pivot_error": r1.max_pivot_error,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": ("k_price_csc" if sparse_per_col > 0 else "k_price_seq2"
+                       if (price_name == "seq" or (price_name == "auto" and cols >= 12288))
+                       else "k_price_wave2"),
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_us": 1e3 * price_ms / max(price_launches, 1),
+            "launches": price_launches,
+            "algorithmic_bytes_per_launch": price_bytes / max(price_launches, 1),
+        },
+    }
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +203,8 @@ def main() -> int:
     ap.add_argument("--numerics", choices=["fast", "strict"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc-traffic", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the 32768x65536 measurement that rides along with the default run")
     ap.add_argument("--sparse-per-col", type=int, default=0,
                     help="generator G2: this many nonzeros per column, matrix kept CSC on the device")
     ap.add_argument("--force-sharded", action="store_true",
@@ -134,81 +226,25 @@ def main() -> int:
 
     traffic = None if args.no_pmc_traffic else pmc_traffic(args)  # children first: no GPU state yet
 
-    from dantzig_amd import _ffi, core
+    from dantzig_amd import _ffi
 
     # one HIP runtime per process: the library's.  dzg_solver_run returns after synchronising
     # its stream, which brackets the timed region the way torch.cuda.synchronize() would.
     _ffi.require_gpu()
-    t_gen = time.perf_counter()
-    if args.sparse_per_col > 0:
-        cp, ri, val, b, c = core.gen_sparse_lp(args.seed, args.rows, args.cols, args.sparse_per_col)
-        lp = core.CoreLP.from_csc(args.rows, cp, ri, val, b, c)
-    else:
-        a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
-        lp = core.CoreLP.from_inequality_form(a, b, c)
-    t_gen = time.perf_counter() - t_gen
-    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[args.price]
-    numerics = core.FAST if args.numerics == "fast" else core.STRICT
-    t_up = time.perf_counter()
-    solver = core.Solver(lp, numerics=numerics, price_kernel=price,
-                         profile=1 << _ffi.K_PRICE, poll_interval=50)
-    t_up = time.perf_counter() - t_up
-
-    status = solver.run(args.warmup) if args.warmup > 0 else "iter_limit"
-    r0 = solver.result(log=False)
-    t0 = time.perf_counter()
-    if status == "iter_limit":
-        status = solver.run(args.steps)
-    t1 = time.perf_counter()
-    r1 = solver.result(log=False)
-    solver.close()
-
-    steps_done = r1.iterations - r0.iterations
-    elapsed = t1 - t0
-    price_ms = r1.kernel_ms["price"] - r0.kernel_ms["price"]
-    price_launches = r1.kernel_launches["price"] - r0.kernel_launches["price"]
-    price_bytes = r1.price_bytes - r0.price_bytes
-    achieved = (price_bytes / 1e9) / (price_ms / 1e3) if price_ms > 0 else float("nan")
-    out = {
-        "metric": "simplex_iterations_per_sec",
-        "value": steps_done / elapsed if elapsed > 0 else float("nan"),
-        "unit": "iterations/s",
-        "n_gpus": 1,
-        "steps": steps_done,
-        "warmup": r0.iterations,
-        "ms_per_step": 1e3 * elapsed / max(steps_done, 1),
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": (f"dense random LP {args.rows}x{args.cols} fp64, generator G1 seed {args.seed}"
-                         if args.sparse_per_col <= 0 else
-                         f"sparse random LP {args.rows}x{args.cols} fp64, {args.sparse_per_col} "
-                         f"nonzeros per column (CSC), generator G2 seed {args.seed}"),
-            "numerics": r1.numerics,
-            "price_kernel": args.price,
-            "status_after_timed_region": status,
-            "requested_steps": args.steps,
-            "lp_generation_s": round(t_gen, 3),
-            "upload_s": round(t_up, 3),
-            "max_pivot_error": r1.max_pivot_error,
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": ("k_price_csc" if args.sparse_per_col > 0 else "k_price_seq2" if (args.price == "seq" or (args.price == "auto" and args.cols >= 12288)) else "k_price_wave2"),
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic["bytes_per_launch"] if traffic else None,
-            "traffic_detail": traffic,
-            "avg_launch_us": 1e3 * price_ms / max(price_launches, 1),
-            "launches": price_launches,
-            "algorithmic_bytes_per_launch": price_bytes / max(price_launches, 1),
-        },
-    }
+    out = measure(args.rows, args.cols, args.seed, args.sparse_per_col, args.price, args.numerics,
+                  args.steps, args.warmup)
+    out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
+    out["roofline"]["traffic_detail"] = traffic
+    if secondary_wanted(args):
+        # the LP the north star's multi-GPU target is quoted on (config 5), on this one GPU too, so
+        # that the per-N lines of a scaling run can be compared on it as well as on config 3
+        try:
+            sec = measure(SECONDARY["rows"], SECONDARY["cols"], SECONDARY["seed"], 0, "auto", "fast",
+                          SECONDARY["steps"], SECONDARY["warmup"])
+            out["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step",
+                                                    "config", "roofline")}
+        except Exception as exc:  # never lose the primary line to the secondary workload
+            out["secondary"] = {"error": f"{type(exc).__name__}: {exc}"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, 2 * args.cpu_sample_rows, 1002,
                                            args.cpu_sample_pivots, args.rows)

@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-pthread"]
         subprocess.check_call(cmd)
     if verbose:
         print("built", LIB)

@@ -32,6 +32,7 @@ EXPORTS = [
     "dzg_shard_record_doubles", "dzg_shard_phase1", "dzg_shard_phase2", "dzg_shard_phase3",
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
+    "dzg_gen_dense_lp_block",
 ]
 
 
@@ -52,6 +53,7 @@ class Opts(C.Structure):
         ("log_capacity", C.c_int64), ("poll_interval", C.c_int32), ("profile", C.c_int32),
         ("col_begin", C.c_int64), ("col_end", C.c_int64), ("rank", C.c_int32),
         ("world", C.c_int32), ("stream", C.c_void_p), ("refactor_interval", C.c_int64),
+        ("a_is_block", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -124,6 +126,9 @@ def lib() -> C.CDLL:
         _lib.dzg_opts_default.restype = None
         _lib.dzg_gen_dense_lp.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p]
+        _lib.dzg_gen_dense_lp_block.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64,
+                                                C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                C.c_void_p]
         _lib.dzg_solver_run.argtypes = [C.c_void_p, C.c_int64]
         _lib.dzg_solver_result.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dzg_solver_destroy.argtypes = [C.c_void_p]

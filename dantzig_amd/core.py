@@ -34,6 +34,10 @@ class CoreLP:
     col_ptr: np.ndarray | None = None
     row_idx: np.ndarray | None = None
     val: np.ndarray | None = None
+    # column sharding: `a` holds only the structural columns [block[0], block[1]) of an LP with
+    # n_struct_full structural columns (opts.a_is_block); everything else is complete
+    block: tuple | None = None
+    n_struct_full: int | None = None
 
     @property
     def m(self) -> int:
@@ -41,6 +45,8 @@ class CoreLP:
 
     @property
     def n_struct(self) -> int:
+        if self.n_struct_full is not None:
+            return int(self.n_struct_full)
         return int(self.a.shape[1]) if self.a is not None else len(self.col_ptr) - 1
 
     @property
@@ -57,6 +63,20 @@ class CoreLP:
                    basis=np.arange(ns, ns + m, dtype=np.int64),
                    nonbasis=np.arange(ns, dtype=np.int64), x=f64(b).copy(), z=-f64(c),
                    var_col=None, constant=constant)
+
+    @classmethod
+    def from_inequality_block(cls, a_block, b, c, begin: int, end: int,
+                              constant: float = 0.0) -> "CoreLP":
+        """One rank's view of from_inequality_form: `a_block` = columns [begin, end) of A."""
+        a_block = np.asarray(a_block, dtype=np.float64)
+        m, ns = a_block.shape[0], len(c)
+        if a_block.shape[1] != end - begin or not 0 <= begin <= end <= ns:
+            raise ValueError("a_block does not match [begin, end)")
+        return cls(a=a_block, c=np.concatenate([f64(c), np.zeros(m)]),
+                   basis=np.arange(ns, ns + m, dtype=np.int64),
+                   nonbasis=np.arange(ns, dtype=np.int64), x=f64(b).copy(), z=-f64(c),
+                   var_col=None, constant=constant, block=(int(begin), int(end)),
+                   n_struct_full=ns)
 
     @classmethod
     def from_csc(cls, m, col_ptr, row_idx, val, b, c, constant: float = 0.0) -> "CoreLP":
@@ -114,6 +134,10 @@ class Solver:
                              float(lp.constant), ptr(k["basis"]), ptr(k["nonbasis"]),
                              ptr(k["x"]), ptr(k["z"]), ptr(k["col_ptr"]), ptr(k["row_idx"]),
                              ptr(k["val"]))
+        if lp.block is not None:
+            if (opts.get("col_begin"), opts.get("col_end")) != tuple(lp.block):
+                raise ValueError("a column-block LP needs a sharded solver on exactly that block")
+            opts["a_is_block"] = 1
         self._opts = _ffi.default_opts(**opts)
         self._h = C.c_void_p(None)
         rc = _ffi.lib().dzg_solver_create(C.byref(self._c_lp), C.byref(self._opts),
@@ -195,6 +219,18 @@ def gen_dense_lp(seed: int, m: int, n_struct: int):
     rc = _ffi.lib().dzg_gen_dense_lp(C.c_uint64(seed), m, n_struct, ptr(a), m, ptr(b), ptr(c))
     _ffi.check(rc, "dzg_gen_dense_lp")
     return a.T, b, c
+
+
+def gen_dense_lp_block(seed: int, m: int, n_struct: int, begin: int, end: int):
+    """Generator G1, columns [begin, end) of A only (bit-identical to that slice of
+    gen_dense_lp); b and c are complete.  Returns (A block (m, end-begin), b, c)."""
+    a = np.empty((max(end - begin, 1), m), dtype=np.float64)
+    b = np.empty(m)
+    c = np.empty(n_struct)
+    rc = _ffi.lib().dzg_gen_dense_lp_block(C.c_uint64(seed), m, n_struct, begin, end, ptr(a), m,
+                                           ptr(b), ptr(c))
+    _ffi.check(rc, "dzg_gen_dense_lp_block")
+    return a[:end - begin].T, b, c
 
 
 def gen_sparse_lp(seed: int, m: int, n_struct: int, per_col: int):

@@ -38,6 +38,8 @@ struct DzgCtl {
     // sharded: z, zbar, dz of the entering position as published by its owner
     double zr, zbar_r, dz_r;
     int use_record;      // 1: k_fast_pivot takes zr/zbar_r/dz_r instead of its local z arrays
+    int del_last;        // >= 0: k_fast_update deletes a compact column of Binv0 (an entering
+    int del_ce;          //       slack): column del_ce := column del_last, column del_last := 0
     int pad2;
     long long nb_nnz;     // sparse mode: stored entries of the owned nonbasic structural columns
     double max_pivot_err; // FAST health: max |dx_p + dz_r| / max(|dx_p|, |dz_r|) over all pivots

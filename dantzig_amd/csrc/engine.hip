@@ -266,7 +266,9 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     }
     d.xstride = 8 + ((long long)m + 7) / 8 * 8;
     const int nloc = d.col1 - d.col0; // structural columns resident on this device
-    const double *a_host = lp->a ? lp->a + (size_t)d.col0 * (size_t)lp->lda : nullptr;
+    const double *a_host = !lp->a ? nullptr
+                           : (o.a_is_block && d.world > 1) ? lp->a
+                                                           : lp->a + (size_t)d.col0 * (size_t)lp->lda;
 
     d.csc = (ns > 0 && !lp->a) ? 1 : 0;
     if (d.csc) {
@@ -381,6 +383,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     c0.status = DZG_RUNNING;
     c0.iter_stop = o.max_iter;
     c0.enter_pos = c0.leave_pos = -1;
+    c0.del_ce = c0.del_last = -1;
     c0.nb_struct = nb_struct;
     HIP_OK(hipMemcpyAsync(d.ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, s->st));
     *s->h_ctl = c0;

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
     double *log_mu, long long log_cap)
 {
-    __shared__ int s_ok, s_k, s_ce, s_last, s_ci, s_cj;
+    __shared__ int s_ok, s_k, s_ci, s_cj;
     // hop 1: the whole control block in one go (a couple of cache lines); every later decision
     // uses this snapshot, and only the fields that change are written back at the end
     const DzgCtl c = *ctl;
@@ -483,24 +483,15 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
         binv[(long long)p * ldb + k] = 1.0; // columns >= ncompact are kept zero
         s_k = k + 1;
     }
-    // ---- an entering slack makes the column of its row the unit vector e_p again
+    // ---- an entering slack makes the column of its row the unit vector e_p again: its compact
+    // column is deleted (swap with the last).  The books are kept here; the m-row column move
+    // itself is done by k_fast_update on the whole chip (ctl->del_ce / del_last).
+    int del_ce = -1, del_last = -1;
     if (cj < 0) {
-        __syncthreads();
         const int re = -1 - cj;
-        if (tid == 0) {
-            s_ce = dslot[re];
-            s_last = s_k - 1;
-        }
-        __syncthreads();
-        const int ce = s_ce, last = s_last;
-        for (int i = tid; i < m; i += blockDim.x) {
-            double *row = binv + (long long)i * ldb;
-            if (ce != last) row[ce] = row[last];
-            row[last] = 0.0;
-        }
         for (int t = tid; t < neta; t += blockDim.x) W[(long long)t * ldw + re] = 0.0;
-        __syncthreads();
         if (tid == 0) {
+            const int ce = dslot[re], last = s_k - 1;
             if (ce != last) {
                 const int lr = drow[last];
                 drow[ce] = lr;
@@ -508,6 +499,8 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
             }
             dslot[re] = -1;
             s_k = last;
+            del_ce = ce;
+            del_last = last;
         }
     }
     if (tid != 0) return;
@@ -552,6 +545,8 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     ctl->enter_var = vj;
     ctl->leave_var = vi;
     ctl->ncompact = s_k;
+    ctl->del_ce = del_ce;
+    ctl->del_last = del_last;
     ctl->neta = neta + 1;
     ctl->max_pivot_err = max_err;
     ctl->iter = it + 1;
@@ -572,11 +567,20 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
                                                      int *fpx_k, double *fpz_r, int *fpz_k,
                                                      const double *__restrict__ v,
                                                      double *__restrict__ U, long long ldu,
-                                                     double *__restrict__ W, long long ldw)
+                                                     double *__restrict__ W, long long ldw,
+                                                     double *__restrict__ binv, long long ldb)
 {
     const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
     const int p = c.leave_pos, r = c.enter_pos;
+    if (!only_partials && c.del_last >= 0) { // compact column delete booked by k_fast_pivot
+        const int ce = c.del_ce, last = c.del_last;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+            double *row = binv + (long long)i * ldb;
+            if (ce != last) row[ce] = row[last];
+            row[last] = 0.0;
+        }
+    }
     // eta of the pivot k_fast_pivot just booked (neta already counts it): u = (dx - e_p)/dx_p,
     // w = v; if a slack entered, its row of W is structurally zero (its column became e_p)
     const int teta = c.neta - 1;
@@ -894,7 +898,7 @@ void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
     hipLaunchKernelGGL(k_fast_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
                        d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.nonbasis, d.var_col, d.col0, d.col1,
                        d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.v, d.U, d.ldw, d.W,
-                       d.ldw);
+                       d.ldw, d.binv, d.ldb);
 }
 
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)

@@ -119,6 +119,11 @@ typedef struct {
     int64_t refactor_interval; /* FAST: rebuild the basis inverse from scratch (blocked LU with
                                  partial pivoting, fp64-MFMA trailing updates) every this many
                                  pivots; 0 = never (the eta file is still folded in every 64)  */
+    int32_t a_is_block;       /* column sharding, dense: 1 = lp->a holds ONLY this rank's columns
+                                 [col_begin, col_end) (column col_begin first), so a rank never
+                                 materialises the other ranks' part of the matrix; 0 = lp->a is
+                                 the whole m x n_struct matrix and the block is taken from it   */
+    int32_t reserved0;
 } dzg_opts;
 
 typedef struct {
@@ -265,6 +270,12 @@ int dzg_gen_sparse_lp(uint64_t seed, int64_t m, int64_t n_struct, int64_t per_co
  * a[lda*n_struct] column-major, b[m], c[n_struct]. */
 int dzg_gen_dense_lp(uint64_t seed, int64_t m, int64_t n_struct, double *a, int64_t lda,
                      double *b, double *c);
+
+/* The same LP, bit for bit, but only columns [col_begin, col_end) of A are produced
+ * (a_block[lda*(col_end-col_begin)]); b[m] and c[n_struct] are complete.  What one rank of a
+ * column-sharded solve needs (pair with opts.a_is_block = 1). */
+int dzg_gen_dense_lp_block(uint64_t seed, int64_t m, int64_t n_struct, int64_t col_begin,
+                           int64_t col_end, double *a_block, int64_t lda, double *b, double *c);
 
 /* ---- column sharding over several GPUs, one process per GPU ------------------------
  * The host (torch.distributed over RCCL, or any collective layer) moves the small

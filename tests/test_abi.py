@@ -113,3 +113,55 @@ def test_malformed_lps_are_rejected_before_any_device_work():
     c_lp.lda = 3  # lda < m
     k["basis"][0] = 6
     assert _ffi.lib().dzg_solver_create(C.byref(c_lp), None, C.byref(h)) == _ffi.E_ARG
+
+
+def _g1_sequential(seed, m, ns):
+    """Generator G1 written out draw by draw: the definition the threaded,
+    seekable C++ generator must reproduce bit for bit."""
+    mask = (1 << 64) - 1
+    state = seed
+
+    def u01():
+        nonlocal state
+        state = (state + 0x9E3779B97F4A7C15) & mask
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        z ^= z >> 31
+        return (z >> 11) * 2.0 ** -53
+
+    a = np.empty((m, ns))
+    for j in range(ns):
+        for i in range(m):
+            a[i, j] = 2.0 * u01() - 1.0
+    x0 = [u01() for _ in range(ns)]
+    y0 = [u01() for _ in range(m)]
+    rb = [u01() for _ in range(m)]
+    rc = [u01() for _ in range(ns)]
+    b = np.zeros(m)
+    for j in range(ns):
+        for i in range(m):
+            b[i] = b[i] + a[i, j] * x0[j]
+    b = np.array([b[i] + rb[i] for i in range(m)])
+    c = np.empty(ns)
+    for j in range(ns):
+        acc = 0.0
+        for i in range(m):
+            acc = acc + a[i, j] * y0[i]
+        c[j] = acc - rc[j]
+    return a, b, c
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_dense_generator_matches_its_sequential_definition(threads, monkeypatch):
+    monkeypatch.setenv("DZG_GEN_THREADS", threads)
+    m, ns, seed = 13, 29, 77
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    ea, eb, ec = _g1_sequential(seed, m, ns)
+    assert np.array_equal(a, ea) and np.array_equal(b, eb) and np.array_equal(c, ec)
+    # a column block is that slice of the same LP, with complete b and c
+    for begin, end in [(0, ns), (0, 10), (10, 19), (19, 29), (7, 7)]:
+        ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)
+        assert ab.shape == (m, end - begin)
+        assert np.array_equal(ab, ea[:, begin:end])
+        assert np.array_equal(bb, eb) and np.array_equal(cb, ec)

@@ -116,6 +116,35 @@ def test_sharded_lockstep_matches_oracle(world, seed, m, ns):
 
 
 @pytest.mark.gpu
+def test_sharded_lockstep_from_column_blocks():
+    """Each rank is given ONLY its own columns of A (gen_dense_lp_block + opts.a_is_block), as in
+    a multi-GPU run of an LP too large to materialise per process: same pivots as the oracle."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import ShardedSolver, col_range, run_lockstep
+
+    world, seed, m, ns = 3, 37, 72, 150
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    solvers = []
+    try:
+        for r in range(world):
+            begin, end = col_range(ns, r, world)
+            ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)
+            lp = core.CoreLP.from_inequality_block(ab, bb, cb, begin, end)
+            solvers.append(ShardedSolver(lp, r, world, poll_interval=16,
+                                         stream=solvers[0].stream if solvers else 0))
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == want.status == "optimal"
+    for res in results:
+        assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+        assert abs(res.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+
+
+@pytest.mark.gpu
 def test_rccl_single_rank_loop():
     """The native RCCL loop with a communicator of one rank (all a 1-GPU box can host): loads
     librccl, ncclCommInitRank, two ncclAllGather per iteration on the solver's stream."""
