@@ -161,9 +161,17 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
 def bench_main(args, rank: int, world: int, local_rank: int) -> int:
     import datetime
 
+    import os
+    import sys
+
     import torch
     import torch.distributed as dist
 
+    # stdout carries exactly one JSON line: whatever gloo / RCCL print from native code while
+    # they start up (version banners) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     _ffi.require_gpu()
     # gloo: bootstrap (ncclUniqueId) + barriers only; a rank that dies must not hang the others
     dist.init_process_group("gloo", rank=rank, world_size=world,
@@ -177,9 +185,10 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
                                local_rank)
         out["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step",
                                                 "config", "roofline")}
-    if rank == 0:
-        print(json.dumps(out))
     dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     return 0
 
 
