@@ -91,7 +91,7 @@ struct dzg_solver {
     double *rfG = nullptr, *rfX = nullptr;
     long long rf_ld = 0;
     int *rf_piv = nullptr, *rf_spos = nullptr, *rf_scode = nullptr, *rf_lpos = nullptr,
-        *rf_lrow = nullptr, *rf_counts = nullptr;
+        *rf_lrow = nullptr, *rf_counts = nullptr, *rf_lslot = nullptr;
     long long since_refactor = 0;
     // STRICT: the O(m) launches of one basis solve, captured once and replayed (hipGraph)
     hipGraphExec_t g_solve[2] = {nullptr, nullptr}; // [0] B dx = a_j, [1] B^T v = e_p
@@ -395,9 +395,9 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         for (int p = 0; p < m; ++p)
             if (var_col[basis[p]] >= 0) slack_basis = false;
         if (!slack_basis) {
-            if (d.csc || d.world > 1)
-                return fail(DZG_E_ARG, "a non-slack starting basis needs dense, unsharded input "
-                                       "in FAST numerics (use STRICT otherwise)");
+            if (d.world > 1)
+                return fail(DZG_E_ARG, "a non-slack starting basis needs unsharded input in FAST "
+                                       "numerics");
             if (o.refactor_interval == 0) o.refactor_interval = -1; // reserve the workspace
             s->opts.refactor_interval = o.refactor_interval;
         }
@@ -418,8 +418,9 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));
         TRY(dev_alloc(s, &d.fpx_k, np)); TRY(dev_alloc(s, &d.fpz_k, np));
         TRY(dev_alloc(s, &d.rx_k, np)); TRY(dev_alloc(s, &d.rz_k, np));
-        if (o.refactor_interval != 0 && d.csc)
-            return fail(DZG_E_ARG, "refactorisation is not available for sparse (CSC) input yet");
+        if (o.refactor_interval != 0 && d.world > 1)
+            return fail(DZG_E_ARG, "refactorisation needs every basic column on the device: not "
+                                   "available for a column-sharded solver");
         if (o.refactor_interval != 0) {
             s->rf_ld = ((long long)m + 15) / 16 * 16 + 16;
             TRY(dev_alloc(s, &s->rfG, (size_t)(m ? m : 1) * (size_t)s->rf_ld));
@@ -427,6 +428,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             TRY(dev_alloc(s, &s->rf_piv, (size_t)m)); TRY(dev_alloc(s, &s->rf_spos, (size_t)m));
             TRY(dev_alloc(s, &s->rf_scode, (size_t)m)); TRY(dev_alloc(s, &s->rf_lpos, (size_t)m));
             TRY(dev_alloc(s, &s->rf_lrow, (size_t)m)); TRY(dev_alloc(s, &s->rf_counts, 4));
+            TRY(dev_alloc(s, &s->rf_lslot, (size_t)(m ? m : 1)));
         }
         dzg_launch_fast_init(d, s->st);
         dzg_launch_fast_update(d, 1, s->st); // first-pivot partials of the initial state
@@ -556,7 +558,7 @@ static int refactor_now(dzg_solver *s)
     if (counts[0] != s->h_ctl->ncompact)
         return fail(DZG_E_DEVICE, "refactor: structural basics != dense columns");
     dzg_launch_refactor(d, counts[0], counts[1], s->rfG, s->rfX, s->rf_ld, s->rf_piv, s->rf_spos,
-                        s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_counts + 2, s->st);
+                        s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_lslot, s->rf_counts + 2, s->st);
     s->since_flush = 0;
     s->since_refactor = 0;
     s->refactors += 1;

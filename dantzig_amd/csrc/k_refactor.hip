@@ -139,6 +139,50 @@ __global__ __launch_bounds__(256) void k_ref_gather(int k, const double *__restr
     X[(long long)a * ldg + b] = (a == b) ? 1.0 : 0.0;
 }
 
+// Sparse (CSC) input: the same two gathers as scatters.  rowmap[i] = compact index of row i in
+// the target (dslot for G, the basic-slack list index for As), < 0: row not wanted.
+// grid = k workgroups (one per structural basic column); the targets are zeroed beforehand.
+__global__ __launch_bounds__(256) void k_ref_scatter_csc(int k, const long long *__restrict__ cptr,
+                                                         const int *__restrict__ ridx,
+                                                         const double *__restrict__ cval, int col0,
+                                                         const int *__restrict__ scode,
+                                                         const int *__restrict__ rowmap,
+                                                         double *__restrict__ T, long long ldt)
+{
+    const int b = blockIdx.x;
+    if (b >= k) return;
+    const int code = scode[b] - col0;
+    for (long long e = cptr[code] + threadIdx.x; e < cptr[code + 1]; e += blockDim.x) {
+        const int a = rowmap[ridx[e]];
+        if (a >= 0) T[(long long)a * ldt + b] = cval[e];
+    }
+}
+
+// X = I, G = 0 (k x k);   grid (ceil(k/256), k)
+__global__ __launch_bounds__(256) void k_ref_identity(int k, double *__restrict__ G,
+                                                      double *__restrict__ X, long long ldg)
+{
+    const int a = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= k) return;
+    G[(long long)a * ldg + b] = 0.0;
+    X[(long long)a * ldg + b] = (a == b) ? 1.0 : 0.0;
+}
+
+// lslot[row] = index of the row in the basic-slack list, -1 for the other rows
+__global__ __launch_bounds__(256) void k_ref_lslot(int m, int nl, const int *__restrict__ lrow,
+                                                   int *__restrict__ lslot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) lslot[i] = -1;
+}
+__global__ __launch_bounds__(256) void k_ref_lslot_fill(int nl, const int *__restrict__ lrow,
+                                                        int *__restrict__ lslot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nl) lslot[lrow[i]] = i;
+}
+
 // panel j0..j0+nbw: unblocked LU with partial pivoting inside the panel columns (one workgroup)
 __global__ __launch_bounds__(1024) void k_ref_panel(int k, int j0, int nbw, double *__restrict__ G,
                                                     long long ldg, int *__restrict__ piv,
@@ -301,13 +345,19 @@ static void gemm_sub(int M, int N, int K, const double *A, long long lda, const 
 }
 
 void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, long long ldg,
-                         int *piv, int *spos, int *scode, int *lpos, int *lrow, int *singular,
-                         hipStream_t st)
+                         int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
+                         int *singular, hipStream_t st)
 {
     hipMemsetAsync(singular, 0, sizeof(int), st);
     if (k > 0) {
-        hipLaunchKernelGGL(k_ref_gather, dim3((k + 255) / 256, k), dim3(256), 0, st, k, d.A, d.lda,
-                           d.col0, d.drow, scode, G, X, ldg);
+        if (d.csc) {
+            hipLaunchKernelGGL(k_ref_identity, dim3((k + 255) / 256, k), dim3(256), 0, st, k, G, X, ldg);
+            hipLaunchKernelGGL(k_ref_scatter_csc, dim3(k), dim3(256), 0, st, k, d.cptr, d.ridx, d.cval,
+                               d.col0, scode, d.dslot, G, ldg);
+        } else {
+            hipLaunchKernelGGL(k_ref_gather, dim3((k + 255) / 256, k), dim3(256), 0, st, k, d.A, d.lda,
+                               d.col0, d.drow, scode, G, X, ldg);
+        }
         // ---- LU of G with the forward substitution of X riding along
         for (int j0 = 0; j0 < k; j0 += NB) {
             const int nbw = (k - j0) < NB ? (k - j0) : NB;
@@ -346,8 +396,18 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
                            d.binv, d.ldb);
         // ---- Binv0 rows of the basic slacks: -A[r', S] * X   (G is free now: reuse it for A[r', S])
         if (nl > 0) {
-            hipLaunchKernelGGL(k_ref_gather_slack, dim3((k + 255) / 256, nl), dim3(256), 0, st, k, d.A,
-                               d.lda, d.col0, lrow, scode, G, ldg);
+            if (d.csc) {
+                hipMemsetAsync(G, 0, sizeof(double) * (size_t)nl * (size_t)ldg, st);
+                hipLaunchKernelGGL(k_ref_lslot, dim3((d.m + 255) / 256), dim3(256), 0, st, d.m, nl, lrow,
+                                   lslot);
+                hipLaunchKernelGGL(k_ref_lslot_fill, dim3((nl + 255) / 256), dim3(256), 0, st, nl, lrow,
+                                   lslot);
+                hipLaunchKernelGGL(k_ref_scatter_csc, dim3(k), dim3(256), 0, st, k, d.cptr, d.ridx,
+                                   d.cval, d.col0, scode, lslot, G, ldg);
+            } else {
+                hipLaunchKernelGGL(k_ref_gather_slack, dim3((k + 255) / 256, nl), dim3(256), 0, st, k,
+                                   d.A, d.lda, d.col0, lrow, scode, G, ldg);
+            }
             hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
                                nl, k, k, G, ldg, X, ldg, d.binv, d.ldb, (const int *)lpos);
         }

@@ -400,3 +400,44 @@ def test_fast_warm_start_from_a_non_slack_basis(core):
     assert _log(strict) == _log(want)
     assert _log(fast) == _log(want)
     assert abs(fast.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+
+
+@pytest.mark.parametrize("seed,m,ns,per_col,interval", [(67, 80, 200, 4, 23), (68, 256, 700, 6, 64)])
+def test_sparse_fast_refactor_keeps_pivot_sequence(core, seed, m, ns, per_col, interval):
+    """CSC input: the refactorisation gathers its k x k block and the basic-slack rows straight
+    from the sparse columns; periodic rebuilds must not change a pivot."""
+    lp, want = _oracle_sparse(core, seed, m, ns, per_col)
+    got = core.solve(lp, numerics=core.FAST, refactor_interval=interval, poll_interval=8)
+    assert got.status == want.status
+    assert _log(got) == _log(want)
+    if want.status == "optimal":
+        assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+    assert got.max_pivot_error < 1e-9
+
+
+def test_sparse_fast_warm_start(core):
+    """Warm start from a non-slack basis with the matrix kept in CSC on the device."""
+    m, ns, per_col = 70, 180, 4
+    cp, ri, val, b, c = core.gen_sparse_lp(69, m, ns, per_col)
+    col_ptr = np.concatenate([cp, cp[-1] + 1 + np.arange(m)])
+    row_idx = np.concatenate([ri.astype(np.int64), np.arange(m)])
+    vals = np.concatenate([val, np.ones(m)])
+    cc = np.concatenate([c, np.zeros(m)])
+    sf0 = ora.StdForm(m=m, n=ns + m, col_ptr=col_ptr, row_idx=row_idx, val=vals, c=cc, constant=0.0,
+                      basis=np.arange(ns, ns + m), nonbasis=np.arange(ns), x=b.copy(), z=-c)
+    first = ora.simplex_solve(sf0, max_iter=20)
+    assert first.status == "iter_limit" and (first.basis < ns).sum() > 3
+    full = np.zeros((m, ns + m))
+    for j in range(ns + m):
+        full[row_idx[col_ptr[j]:col_ptr[j + 1]], j] = vals[col_ptr[j]:col_ptr[j + 1]]
+    xb = np.linalg.solve(full[:, first.basis], b)
+    y = np.linalg.solve(full[:, first.basis].T, cc[first.basis])
+    zn = full[:, first.nonbasis].T @ y - cc[first.nonbasis]
+    sf = ora.StdForm(m=m, n=ns + m, col_ptr=col_ptr, row_idx=row_idx, val=vals, c=cc, constant=0.0,
+                     basis=first.basis.copy(), nonbasis=first.nonbasis.copy(), x=xb, z=zn)
+    want = ora.simplex_solve(sf)
+    lp = core.CoreLP(a=None, c=cc, basis=first.basis, nonbasis=first.nonbasis, x=xb, z=zn,
+                     col_ptr=cp, row_idx=ri, val=val)
+    fast = core.solve(lp, numerics=core.FAST, poll_interval=8)
+    assert fast.status == want.status
+    assert _log(fast) == _log(want)
