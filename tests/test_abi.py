@@ -165,3 +165,48 @@ def test_dense_generator_matches_its_sequential_definition(threads, monkeypatch)
         assert ab.shape == (m, end - begin)
         assert np.array_equal(ab, ea[:, begin:end])
         assert np.array_equal(bb, eb) and np.array_equal(cb, ec)
+
+
+def _build_c_host(tmp_path):
+    """gcc + include/dantzig_amd.h + the shared library: no Python, no torch in between."""
+    import subprocess
+
+    exe = tmp_path / "readme_lp"
+    libdir = os.path.join(ROOT, "dantzig_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I",
+                           os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_host", "readme_lp.c"), "-o", str(exe),
+                           "-L", libdir, "-ldantzig_amd", f"-Wl,-rpath,{libdir}"])
+    return subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+
+
+def test_plain_c_host_links_and_fails_loudly_without_gpu(tmp_path):
+    if _ffi.lib().dzg_device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu-marked variant")
+    run = _build_c_host(tmp_path)
+    assert run.returncode == 3
+    assert "abi 1 devices 0" in run.stdout
+    assert "device_error" in run.stderr and "no CPU path" in run.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_host_solves_the_readme_lp(tmp_path):
+    """The drop-in boundary used from C: Level 2 on the reference README's LP (expected
+    objective -1.0 at (0, 0, 1), README.md:60-73), Level 1 against the oracle."""
+    from oracle import oracle as ora
+
+    run = _build_c_host(tmp_path)
+    assert run.returncode == 0, run.stderr
+    lines = {ln.split()[0]: dict(kv.split("=") for kv in ln.split()[1:])
+             for ln in run.stdout.splitlines() if ln.startswith("level")}
+    l2 = lines["level2"]
+    assert l2["status"] == "optimal"
+    assert (float(l2["objective"]), float(l2["x"]), float(l2["y"]), float(l2["z"])) == (-1.0, 0.0, 0.0, 1.0)
+    a, b, c = core.gen_dense_lp(seed=7, m=24, n_struct=40)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    l1 = lines["level1"]
+    assert l1["status"] == want.status == "optimal"
+    assert int(l1["iterations"]) == want.iterations
+    assert float(l1["objective"]) == want.objective           # STRICT: bit-identical
+    k, e, l, _ = want.pivots[0]
+    assert l1["first_pivot"] == f"{k}:{e}:{l}"
