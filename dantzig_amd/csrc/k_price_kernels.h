@@ -401,6 +401,6 @@ __global__ __launch_bounds__(256) void k_price_csc(
     price_publish(best, rz_r, rz_k);
 }
 
-#define DZG_PRICE_CSC_BLOCKS 512
+#define DZG_PRICE_CSC_BLOCKS 2048
 #define DZG_PRICE_SEQ_BLOCKS 256   // x 4 waves: one workgroup per CU
 #define DZG_PRICE_WAVE_BLOCKS 2048 // x 4 waves
