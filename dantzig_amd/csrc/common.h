@@ -121,6 +121,25 @@ __device__ __forceinline__ double dzg_readlane_f64(double v, int lane)
 #endif // __HIPCC__
 
 // ---------------------------------------------------------------------------------
+// STRICT LU workspace (k_strict.hip): blocked right-looking LU in the reference's operation order
+// ---------------------------------------------------------------------------------
+#define DZG_LU_NB 64  // panel width
+#define DZG_LU_LDP 66 // panel buffer row stride: 64 matrix columns, the right-hand side at [64]
+struct DzgLu {
+    int n;
+    long long ldw;   // row stride of W; columns 0..n-1 = matrix, column n = right-hand side
+    double *W;       // n x ldw, row-major
+    double *P0, *P1; // n x DZG_LU_LDP each: the active part of the panel, ping-pong
+    int *piv;        // n   pivot row of step k (Matrix::factorize's p)
+    int *pz;         // n   1 if the pivot of step k was exactly zero (step skipped)
+    int *ptab;       // DZG_LU_NB x n   row positions per step (see k_strict.hip)
+    double *part_r;  // 2 x nparts   per-workgroup pivot-search maxima, ping-pong
+    int *part_k;     // 2 x nparts
+    int nparts;
+};
+void dzg_lu_layout(int n, DzgLu *w); // fills n, ldw, nparts
+
+// ---------------------------------------------------------------------------------
 // Host-side launch wrappers (defined in the .hip files, called by engine.hip).
 // All take the stream; all kernels early-out unless ctl->status == DZG_RUNNING.
 // ---------------------------------------------------------------------------------
@@ -160,10 +179,7 @@ struct DzgDev {
     double *fpx_r, *fpz_r, *rx_r, *rz_r; // partial candidates (ratios)
     int *fpx_k, *fpz_k, *rx_k, *rz_k;    // partial candidates (positions)
     // strict numerics
-    double *lu;   // m x m row-major workspace
-    double *lt;   // m x m: multipliers, column k contiguous
-    int *piv;     // m
-    double *urow, *krow, *lcol; // m each
+    DzgLu lu;
     double eps;
     // column sharding (world > 1): this rank holds structural columns [col0, col1)
     int col0, col1, rank, world;
@@ -207,8 +223,7 @@ void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, con
 //         B^T y = rhs (transposed == 1, rhs = unit(leave_pos) -> d.v)
 // with the reference's dense LU; `need_kind` < 0 runs unconditionally.
 void dzg_launch_strict_solve(const DzgDev &d, int transposed, hipStream_t st);
-void dzg_launch_lu_raw(int n, double *lu, double *lt, int *piv, double *urow, double *krow,
-                       double *lcol, DzgCtl *ctl, double *b, hipStream_t st);
+void dzg_launch_lu_raw(const DzgLu &w, DzgCtl *ctl, double *x_out, hipStream_t st);
 
 // k_fast.hip
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st);

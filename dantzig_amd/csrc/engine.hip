@@ -436,11 +436,14 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             TRY(refactor_now(s));
         }
     } else {
-        TRY(dev_alloc(s, &d.lu, (size_t)m * (size_t)m));
-        TRY(dev_alloc(s, &d.lt, (size_t)m * (size_t)m));
-        TRY(dev_alloc(s, &d.piv, (size_t)m));
-        TRY(dev_alloc(s, &d.urow, (size_t)m)); TRY(dev_alloc(s, &d.krow, (size_t)m));
-        TRY(dev_alloc(s, &d.lcol, (size_t)m));
+        dzg_lu_layout(m, &d.lu);
+        const size_t mm = (size_t)(m ? m : 1);
+        TRY(dev_alloc(s, &d.lu.W, mm * (size_t)d.lu.ldw));
+        TRY(dev_alloc(s, &d.lu.P0, mm * DZG_LU_LDP)); TRY(dev_alloc(s, &d.lu.P1, mm * DZG_LU_LDP));
+        TRY(dev_alloc(s, &d.lu.piv, mm)); TRY(dev_alloc(s, &d.lu.pz, mm));
+        TRY(dev_alloc(s, &d.lu.ptab, mm * DZG_LU_NB));
+        TRY(dev_alloc(s, &d.lu.part_r, (size_t)2 * d.lu.nparts));
+        TRY(dev_alloc(s, &d.lu.part_k, (size_t)2 * d.lu.nparts));
     }
     if (o.profile) {
         s->ev.resize((size_t)o.poll_interval * DZG_K_COUNT * 2);
@@ -975,37 +978,41 @@ extern "C" int dzg_kernel_lu_solve(int64_t n, const double *a, const double *b, 
     if (n <= 0 || !a || !b || !x_out) return fail(DZG_E_ARG, "bad argument");
     if (dzg_device_count() <= 0) return fail(DZG_E_DEVICE, "no HIP device visible");
     HIP_OK(hipSetDevice(device));
-    const size_t nn = (size_t)n * (size_t)n;
-    double *lu, *lt, *urow, *krow, *lcol, *rhs;
-    int *piv;
+    DzgLu w{};
+    dzg_lu_layout((int)n, &w);
+    double *xo;
     DzgCtl *ctl;
-    HIP_OK(hipMalloc(&lu, sizeof(double) * nn));
-    HIP_OK(hipMalloc(&lt, sizeof(double) * nn));
-    HIP_OK(hipMalloc(&urow, sizeof(double) * n));
-    HIP_OK(hipMalloc(&krow, sizeof(double) * n));
-    HIP_OK(hipMalloc(&lcol, sizeof(double) * n));
-    HIP_OK(hipMalloc(&rhs, sizeof(double) * n));
-    HIP_OK(hipMalloc(&piv, sizeof(int) * n));
+    HIP_OK(hipMalloc(&w.W, sizeof(double) * (size_t)n * (size_t)w.ldw));
+    HIP_OK(hipMalloc(&w.P0, sizeof(double) * (size_t)n * DZG_LU_LDP));
+    HIP_OK(hipMalloc(&w.P1, sizeof(double) * (size_t)n * DZG_LU_LDP));
+    HIP_OK(hipMalloc(&w.piv, sizeof(int) * n));
+    HIP_OK(hipMalloc(&w.pz, sizeof(int) * n));
+    HIP_OK(hipMalloc(&w.ptab, sizeof(int) * (size_t)n * DZG_LU_NB));
+    HIP_OK(hipMalloc(&w.part_r, sizeof(double) * 2 * (size_t)w.nparts));
+    HIP_OK(hipMalloc(&w.part_k, sizeof(int) * 2 * (size_t)w.nparts));
+    HIP_OK(hipMalloc(&xo, sizeof(double) * n));
     HIP_OK(hipMalloc(&ctl, sizeof(DzgCtl)));
     DzgCtl c0;
     std::memset(&c0, 0, sizeof(c0));
     c0.status = DZG_RUNNING;
     HIP_OK(hipMemcpy(ctl, &c0, sizeof(c0), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(lu, a, sizeof(double) * nn, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(rhs, b, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIP_OK(hipMemset(piv, 0, sizeof(int) * n));
-    dzg_launch_lu_raw((int)n, lu, lt, piv, urow, krow, lcol, ctl, rhs, 0);
+    const size_t pitch = sizeof(double) * (size_t)w.ldw, rowb = sizeof(double) * (size_t)n;
+    HIP_OK(hipMemcpy2D(w.W, pitch, a, rowb, rowb, (size_t)n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy2D(w.W + n, pitch, b, sizeof(double), sizeof(double), (size_t)n,
+                       hipMemcpyHostToDevice)); // the right-hand side is column n
+    HIP_OK(hipMemset(w.piv, 0, sizeof(int) * n));
+    dzg_launch_lu_raw(w, ctl, xo, 0);
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpy(x_out, rhs, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (lu_out) HIP_OK(hipMemcpy(lu_out, lu, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(x_out, xo, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (lu_out) HIP_OK(hipMemcpy2D(lu_out, rowb, w.W, pitch, rowb, (size_t)n, hipMemcpyDeviceToHost));
     if (p_out && n > 1) {
         std::vector<int> p((size_t)n);
-        HIP_OK(hipMemcpy(p.data(), piv, sizeof(int) * n, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(p.data(), w.piv, sizeof(int) * n, hipMemcpyDeviceToHost));
         for (int64_t k = 0; k + 1 < n; ++k) p_out[k] = p[(size_t)k];
     }
-    hipFree(lu); hipFree(lt); hipFree(urow); hipFree(krow); hipFree(lcol); hipFree(rhs);
-    hipFree(piv); hipFree(ctl);
+    hipFree(w.W); hipFree(w.P0); hipFree(w.P1); hipFree(w.piv); hipFree(w.pz); hipFree(w.ptab);
+    hipFree(w.part_r); hipFree(w.part_k); hipFree(xo); hipFree(ctl);
     return 0;
 }
 

@@ -32,7 +32,8 @@ def assert_bit_equal(got, want, what=""):
 
 
 # ------------------------------------------------------------------ lu_solve (src/linalg.rs)
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 64, 65, 130, 257])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 63, 64, 65, 66, 127, 128, 129, 130, 257, 513, 2100,
+                               4200])
 def test_lu_solve_bit_exact(core, n):
     rng = np.random.default_rng(100 + n)
     a = rng.uniform(-1, 1, (n, n))
@@ -68,6 +69,47 @@ def test_lu_integer_ties_and_zero_pivot(core):
         ok = np.isfinite(want_x)
         assert_bit_equal(x[ok], want_x[ok])
         assert np.array_equal(np.isnan(x), np.isnan(want_x))
+
+
+def test_lu_zero_pivot_beyond_the_first_panel(core):
+    """An all-zero column in the second 64-column panel: the step is skipped (src/linalg.rs:117)
+    inside the panel AND in the blocked updates of the columns to its right."""
+    rng = np.random.default_rng(11)
+    n = 200
+    a = rng.uniform(-1, 1, (n, n))
+    a[:, 70] = 0.0
+    a[:, 130] = 0.0
+    b = rng.uniform(-1, 1, n)
+    x, lu, p = core.lu_solve(a, b)
+    want_lu, want_p = ora.lu_factorize(a)
+    assert p.tolist() == want_p.tolist()
+    assert_bit_equal(lu, want_lu, "packed LU")
+    want_x = ora.lu_solve(a, b)
+    ok = np.isfinite(want_x)
+    assert_bit_equal(x[ok], want_x[ok], "x")
+    assert np.array_equal(np.isnan(x), np.isnan(want_x))
+
+
+def test_lu_back_substitution_outside_lds():
+    """Right-hand sides too long for LDS stay in the output vector: same bits.  The switch is
+    read once per process, hence the child process."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np\n"
+        "from dantzig_amd import core\n"
+        "from oracle import oracle as ora\n"
+        "rng = np.random.default_rng(3)\n"
+        "for n in (130, 300):\n"
+        "    a = rng.uniform(-1, 1, (n, n)); b = rng.uniform(-1, 1, n)\n"
+        "    x, lu, p = core.lu_solve(a, b)\n"
+        "    assert np.array_equal(x.view(np.int64), ora.lu_solve(a, b).view(np.int64)), n\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                         env=dict(os.environ, DZG_LU_SMALL_LDS="1"), timeout=300)
+    assert run.returncode == 0 and "ok" in run.stdout, run.stderr[-2000:]
 
 
 # ------------------------------------------------------------------ neg_t_dot (src/linalg.rs)
