@@ -107,10 +107,19 @@ def pmc_traffic(args) -> dict | None:
 SECONDARY = {"rows": 32768, "cols": 65536, "seed": 1005, "steps": 300, "warmup": 50}
 
 
+def under_profiler() -> bool:
+    """True when this process was started by rocprofv3 (its tool library is preloaded and has
+    already touched the GPU).  The run is then kept to the primary workload in this one process:
+    no child processes (none may be exec'ed once the GPU is initialised; nested profilers do not
+    mix) and no second workload, so the profiler's per-kernel averages are those of `value`."""
+    return ("ROCP_TOOL_LIBRARIES" in os.environ
+            or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))
+
+
 def secondary_wanted(args) -> bool:
     """The config-5 measurement rides along with the default invocation only."""
-    return (not args.no_secondary and args.rows == 8192 and args.cols == 16384
-            and args.sparse_per_col == 0 and args.numerics == "fast")
+    return (not args.no_secondary and not under_profiler() and args.rows == 8192
+            and args.cols == 16384 and args.sparse_per_col == 0 and args.numerics == "fast")
 
 
 def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, warmup) -> dict:
@@ -224,7 +233,8 @@ def main() -> int:
 
         return sharded.bench_main(args, rank, world, local_rank)
 
-    traffic = None if args.no_pmc_traffic else pmc_traffic(args)  # children first: no GPU state yet
+    # children first: no GPU state yet (and none at all under a profiler)
+    traffic = None if (args.no_pmc_traffic or under_profiler()) else pmc_traffic(args)
 
     from dantzig_amd import _ffi
 
@@ -235,6 +245,8 @@ def main() -> int:
                   args.steps, args.warmup)
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
     out["roofline"]["traffic_detail"] = traffic
+    if under_profiler():
+        out["config"]["under_profiler"] = True
     if secondary_wanted(args):
         # the LP the north star's multi-GPU target is quoted on (config 5), on this one GPU too, so
         # that the per-N lines of a scaling run can be compared on it as well as on config 3
