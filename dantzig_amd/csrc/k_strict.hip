@@ -245,6 +245,84 @@ __global__ __launch_bounds__(256) void k_lu_step(const DzgCtl *ctl, int n, int k
     }
 }
 
+// A whole panel in ONE workgroup when its rows fit in LDS ((n - k0) x 66 doubles: every panel of
+// a matrix up to ~290 rows, and the last panels of any matrix): the elimination steps are
+// separated by workgroup barriers instead of kernel boundaries (~0.5 us instead of ~6 us per
+// step).  Same operations in the same order: pivot search, swap on columns >= k, multipliers,
+// rank-1 update -- here literally in place, as the reference does it.
+__global__ __launch_bounds__(1024) void k_lu_panel_lds(const DzgCtl *ctl, int n, int k0, int nbw,
+                                                       int nsteps, double *__restrict__ W,
+                                                       long long ldw, int *__restrict__ piv,
+                                                       int *__restrict__ pz)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_pan[]; // [(n - k0)][LDP]
+    if (ctl->status != DZG_RUNNING) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int rows = n - k0;
+    for (int r = wave; r < rows; r += nwaves) {
+        const double *wi = W + (long long)(k0 + r) * ldw;
+        if (lane < nbw) s_pan[r * LDP + lane] = wi[k0 + lane];
+        if (lane == 0) s_pan[r * LDP + NB] = wi[n];
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) { // step k = k0 + s, local row index s
+        DzgCand best;
+        best.r = 0.0;
+        best.k = -1;
+        for (int r = s + threadIdx.x; r < rows; r += blockDim.x)
+            best = dzg_better(best, lu_cand(s_pan[r * LDP + s], r));
+        best = dzg_block_best(best);
+        const double akk = s_pan[s * LDP + s];
+        // `x > NaN` is never true: a NaN at (k,k) keeps mu = k (src/linalg.rs:98-105)
+        const int mu = (fabs(akk) != fabs(akk) || best.k < 0) ? s : best.k;
+        const double pivot = s_pan[mu * LDP + s];
+        const bool zero = !(pivot != 0.0);
+        if (threadIdx.x == 0) {
+            piv[k0 + s] = k0 + mu;
+            pz[k0 + s] = zero ? 1 : 0;
+        }
+        __syncthreads(); // everybody has read the pivot before the rows move
+        if (mu != s && wave == 0) { // swap rows k and mu on columns >= k, and the right-hand side
+            if (lane >= s && lane < nbw) {
+                const double a = s_pan[s * LDP + lane];
+                s_pan[s * LDP + lane] = s_pan[mu * LDP + lane];
+                s_pan[mu * LDP + lane] = a;
+            }
+            if (lane == 0) {
+                const double a = s_pan[s * LDP + NB];
+                s_pan[s * LDP + NB] = s_pan[mu * LDP + NB];
+                s_pan[mu * LDP + NB] = a;
+            }
+        }
+        __syncthreads();
+        const double u_c = lane < nbw ? s_pan[s * LDP + lane] : 0.0;
+        const double u_b = s_pan[s * LDP + NB];
+        for (int r = s + 1 + wave; r < rows; r += nwaves) {
+            double *row = s_pan + r * LDP;
+            const double s_k = row[s];
+            // zero pivot: no scaling, no update of the matrix (src/linalg.rs:117-125); LU::solve
+            // still runs b[i] -= b[k] * a(i,k) with the stored entry (src/linalg.rs:288-290)
+            const double l = zero ? s_k : s_k / pivot;
+            if (!zero && lane > s && lane < nbw) {
+                const double adjustment = l * u_c;
+                row[lane] = row[lane] - adjustment;
+            }
+            if (lane == 0) {
+                const double badj = u_b * l;
+                row[NB] = row[NB] - badj;
+            }
+            __builtin_amdgcn_wave_barrier(); // row[s] is read by every lane before lane s rewrites it
+            if (!zero && lane == s) row[s] = l;
+        }
+        __syncthreads();
+    }
+    for (int r = wave; r < rows; r += nwaves) {
+        double *wi = W + (long long)(k0 + r) * ldw;
+        if (lane < nbw) wi[k0 + lane] = s_pan[r * LDP + lane];
+        if (lane == 0) wi[n] = s_pan[r * LDP + NB];
+    }
+}
+
 // ptab[s][p] = position, right after the swap of step k0+s, of the row that ends the panel at
 // position p (the multiplier it met at that step sits there: L is unpermuted).
 __global__ __launch_bounds__(256) void k_lu_ptab(const DzgCtl *ctl, int n, int k0, int nsteps,
@@ -531,6 +609,26 @@ static size_t backsolve_lds_limit()
     return limit;
 }
 
+// dynamic LDS of the single-workgroup panel kernel (same policy)
+static size_t panel_lds_limit()
+{
+    static size_t limit = 0;
+    if (!limit) {
+        limit = 60 * 1024;
+        if (getenv("DZG_LU_SMALL_LDS")) { // test switch: multi-workgroup panel steps at small n too
+            limit = 1;
+            return limit;
+        }
+        const int big = 152 * 1024;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_lu_panel_lds),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess)
+            limit = (size_t)big;
+        else
+            (void)hipGetLastError();
+    }
+    return limit;
+}
+
 // factorise W (columns 0..n-1) with the right-hand side in column n, then back-substitute.
 // RW rows per wave in the panel kernels: few for small matrices (more workgroups in flight),
 // more for large ones (every workgroup re-reduces all per-workgroup maxima of the previous step).
@@ -544,18 +642,25 @@ static void factorize_and_solve_t(const DzgLu &w, DzgCtl *ctl, double *x_out, hi
         const int nbw = (n - k0) < NB ? (n - k0) : NB;
         const int klast = (k0 + nbw - 1) < (n - 2) ? (k0 + nbw - 1) : (n - 2); // last step here
         const int nsteps = klast - k0 + 1;
-        int nparts = (n - k0 + rpg - 1) / rpg;
-        hipLaunchKernelGGL((k_lu_panel_load<RW>), dim3(nparts), dim3(256), 0, st, ctl, n, k0, nbw, w.W,
-                           w.ldw, P[0], w.part_r, w.part_k);
-        for (int k = k0; k <= klast; ++k) {
-            const int par = (k - k0) & 1;
-            const int grid = (n - k + rpg - 1) / rpg;
-            hipLaunchKernelGGL((k_lu_step<RW>), dim3(grid), dim3(256), 0, st, ctl, n, k, k0, nbw,
-                               k == klast ? 1 : 0, P[par], P[par ^ 1], w.W, w.ldw, w.piv, w.pz,
-                               w.part_r + (size_t)par * w.nparts, w.part_k + (size_t)par * w.nparts,
-                               nparts, w.part_r + (size_t)(par ^ 1) * w.nparts,
-                               w.part_k + (size_t)(par ^ 1) * w.nparts);
-            nparts = grid;
+        const size_t pan_lds = sizeof(double) * (size_t)(n - k0) * LDP;
+        if (pan_lds <= panel_lds_limit()) { // the panel's rows fit in one workgroup's LDS
+            hipLaunchKernelGGL(k_lu_panel_lds, dim3(1), dim3(1024), pan_lds, st, ctl, n, k0, nbw, nsteps,
+                               w.W, w.ldw, w.piv, w.pz);
+        } else {
+            int nparts = (n - k0 + rpg - 1) / rpg;
+            hipLaunchKernelGGL((k_lu_panel_load<RW>), dim3(nparts), dim3(256), 0, st, ctl, n, k0, nbw,
+                               w.W, w.ldw, P[0], w.part_r, w.part_k);
+            for (int k = k0; k <= klast; ++k) {
+                const int par = (k - k0) & 1;
+                const int grid = (n - k + rpg - 1) / rpg;
+                hipLaunchKernelGGL((k_lu_step<RW>), dim3(grid), dim3(256), 0, st, ctl, n, k, k0, nbw,
+                                   k == klast ? 1 : 0, P[par], P[par ^ 1], w.W, w.ldw, w.piv, w.pz,
+                                   w.part_r + (size_t)par * w.nparts,
+                                   w.part_k + (size_t)par * w.nparts, nparts,
+                                   w.part_r + (size_t)(par ^ 1) * w.nparts,
+                                   w.part_k + (size_t)(par ^ 1) * w.nparts);
+                nparts = grid;
+            }
         }
         const int rest = n - (k0 + NB);
         if (rest > 0) { // only full panels have columns to their right (nsteps == NB)
@@ -610,5 +715,6 @@ void dzg_lu_layout(int n, DzgLu *w)
     w->ldw = ((long long)n + 1 + 7) / 8 * 8 + 8;
     const int rpg = 4 * rows_per_wave(n);
     w->nparts = (n + rpg - 1) / rpg + 2;
-    (void)backsolve_lds_limit(); // set the kernel attribute outside any stream capture
+    (void)backsolve_lds_limit(); // set the kernel attributes outside any stream capture
+    (void)panel_lds_limit();
 }
