@@ -88,14 +88,16 @@ def test_first_pivots_match_reference_arithmetic(core, lp_data):
     assert np.allclose([p[3] for p in fast.pivots], [p[3] for p in strict.pivots], rtol=1e-12)
 
 
-def test_whole_solve_is_certified_optimal_by_lapack(core):
-    """4096 x 8192 to optimality (about 180 000 pivots), then strong duality on the host: the
-    final basis alone must be primal and dual feasible under LAPACK's arithmetic and the engine's
-    objective must agree to the north star's 1e-9.  (8192 x 16384: tools/full_solve.py,
+@pytest.mark.parametrize("seed,m,ns", [(1006, 4096, 8192), (7, 4096, 2048), (8, 512, 16384),
+                                       (9, 3000, 3000)])
+def test_whole_solve_is_certified_optimal_by_lapack(core, seed, m, ns):
+    """Whole solves (4096 x 8192: about 180 000 pivots; tall, wide and square shapes), then strong
+    duality on the host: the final basis alone must be primal and dual feasible under LAPACK's
+    arithmetic and the engine's objective must agree to the north star's 1e-9.  (8192 x 16384: tools/full_solve.py,
     profiles/r01_full_solve_8192x16384.txt -- 514 893 pivots, gap 7e-13.)"""
     from tests.optimality import certificate
 
-    a, b, c = core.gen_dense_lp(seed=1006, m=4096, n_struct=8192)
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
     lp = core.CoreLP.from_inequality_form(a, b, c)
     res = core.solve(lp, log=False, numerics=core.FAST, poll_interval=256)
     assert res.status == "optimal"
