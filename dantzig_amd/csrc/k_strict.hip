@@ -354,9 +354,11 @@ __global__ __launch_bounds__(256) void k_lu_trail_u(const DzgCtl *ctl, int n, in
                                                     const int *__restrict__ pz,
                                                     const int *__restrict__ ptab)
 {
-    __shared__ double s_l[NB][NB + 1]; // s_l[r][s] = multiplier of block row r at step s
+    // s_x: first the rows BELOW the panel that its swaps touch (staged so that the 64 swaps run
+    // on LDS instead of 64 dependent HBM round trips), afterwards the multipliers
+    __shared__ double s_x[NB][NB + 1];
     __shared__ double s_y[NB][NB + 1]; // s_y[r][c] = block row r, tile column c
-    __shared__ int s_mu[NB], s_pz[NB];
+    __shared__ int s_mu[NB], s_pz[NB], s_slot[NB];
     if (ctl->status != DZG_RUNNING) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k1 = k0 + NB;
@@ -365,13 +367,22 @@ __global__ __launch_bounds__(256) void k_lu_trail_u(const DzgCtl *ctl, int n, in
         s_mu[tid] = piv[k0 + tid];
         s_pz[tid] = pz[k0 + tid];
     }
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e / NB, st = e % NB;
-        s_l[r][st] = r > st ? W[(long long)ptab[(long long)st * n + k0 + r] * ldw + k0 + st] : 0.0;
+    __syncthreads();
+    if (tid < NB) { // a far row hit by several swaps is staged once: slot = first step that hits it
+        int slot = tid;
+        const int mu = s_mu[tid];
+        for (int t = tid - 1; t >= 0; --t)
+            if (s_mu[t] == mu) slot = t;
+        s_slot[tid] = slot;
     }
     const bool live = j0 + lane < n;
     const int jc = live ? j0 + lane : n - 1; // clamped: dead columns are read, never stored
     for (int r = wave; r < NB; r += 4) s_y[r][lane] = W[(long long)(k0 + r) * ldw + jc];
+    __syncthreads();
+    for (int st = wave; st < NB; st += 4) {
+        const int mu = s_mu[st];
+        if (mu >= k1 && s_slot[st] == st) s_x[st][lane] = W[(long long)mu * ldw + jc];
+    }
     __syncthreads();
     if (wave == 0) { // row swaps of the panel, in order (columns >= k), one thread per column
         for (int st = 0; st < NB; ++st) {
@@ -382,11 +393,22 @@ __global__ __launch_bounds__(256) void k_lu_trail_u(const DzgCtl *ctl, int n, in
                 s_y[st][lane] = s_y[mu - k0][lane];
                 s_y[mu - k0][lane] = a;
             } else {
-                double *far = W + (long long)mu * ldw + jc;
-                s_y[st][lane] = *far;
-                if (live) *far = a;
+                const int slot = s_slot[st];
+                s_y[st][lane] = s_x[slot][lane];
+                s_x[slot][lane] = a;
             }
         }
+    }
+    __syncthreads();
+    if (live)
+        for (int st = wave; st < NB; st += 4) {
+            const int mu = s_mu[st];
+            if (mu >= k1 && s_slot[st] == st) W[(long long)mu * ldw + j0 + lane] = s_x[st][lane];
+        }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) { // s_x[r][st] = multiplier of block row r at step st
+        const int r = e / NB, st = e % NB;
+        s_x[r][st] = r > st ? W[(long long)ptab[(long long)st * n + k0 + r] * ldw + k0 + st] : 0.0;
     }
     __syncthreads();
     for (int c0 = wave * 16; c0 < wave * 16 + 16; c0 += 4) { // lane = block row
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(256) void k_lu_trail_u(const DzgCtl *ctl, int n, in
                y3 = s_y[lane][c0 + 3];
         for (int st = 0; st + 1 < NB; ++st) {
             if (s_pz[st]) continue;
-            const double l = s_l[lane][st];
+            const double l = s_x[lane][st];
             const double u0 = dzg_readlane_f64(y0, st), u1 = dzg_readlane_f64(y1, st),
                          u2 = dzg_readlane_f64(y2, st), u3 = dzg_readlane_f64(y3, st);
             if (lane > st) {

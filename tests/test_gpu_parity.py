@@ -515,7 +515,8 @@ def test_whole_solve_follows_the_oracle_pivot_log(core, path):
     assert np.array_equal(got.basis, fx["basis"])
     mu = np.array([p[3] for p in got.pivots])
     # x and xbar are UPDATED vectors in the reference too (src/simplex.rs:262-265): after thousands
-    # of pivots both sides carry ~1e-9 of their own rounding history in mu = -x/xbar (measured:
-    # 6e-9 at mu = 4.4, unchanged by refactorising every 200 pivots), while every decision agrees
-    assert np.all(np.abs(mu - fx["mu"]) <= 1e-8 * np.maximum(1.0, np.abs(fx["mu"])))
+    # of pivots both sides carry their own rounding history in mu = -x/xbar (measured with
+    # tools/mu_diag.py: 6e-9 after 7 692 pivots, 3e-8 after 21 642, unchanged by refactorising
+    # every few hundred pivots), while every decision agrees
+    assert np.all(np.abs(mu - fx["mu"]) <= 1e-7 * np.maximum(1.0, np.abs(fx["mu"])))
     assert abs(got.objective - float(fx["objective"])) <= 1e-9 * max(1.0, abs(float(fx["objective"])))
