@@ -360,8 +360,7 @@ int ora_simplex_solve(ora_simplex *s, int64_t max_iter, int64_t *iterations,
             log[it].mu = mu;
         }
         if (!do_pivot(s, &w, b_i, n_j)) {
-            status = ORA_PANIC; /* safe_divide assert, :466 */
-            ++it;
+            status = ORA_PANIC; /* safe_divide assert, :466: the pivot was chosen, not executed */
             break;
         }
         ++it;
