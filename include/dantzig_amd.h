@@ -217,6 +217,8 @@ typedef struct {
     int64_t m, n;         /* size of the standard form that was solved                  */
 } dzg_model_result;
 
+/* With opts == NULL or numerics AUTO: a FAST run that ends in DZG_SINGULAR / DZG_PANIC is repeated
+ * with STRICT numerics (the reference's arithmetic) and that result is returned. */
 int dzg_model_solve(const dzg_model *model, const dzg_opts *opts, dzg_model_result *res);
 
 /* Host-only: the standard-form builder alone (Simplex::new, src/simplex.rs:123-224).

@@ -268,3 +268,44 @@ def test_degenerate_transportation_model_through_surface():
     ref = linprog(cost.ravel(), A_ub=a, b_ub=b, bounds=(0, None), method="highs")
     sol = problem.solve()
     assert abs(sol.objective_value - ref.fun) <= 1e-9 * abs(ref.fun)
+
+
+def _zero_one_model(seed, ncons=130, nvars=110):
+    """A 0/1 packing model, 240 rows in standard form (> auto_strict_rows): degenerate vertices,
+    0/0 ratios -- data on which an updated explicit inverse loses its footing."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(size=(ncons, nvars)) < 0.25
+    b = rng.integers(0, 4, ncons)
+    c = rng.integers(-1, 6, nvars)
+    xs = [dz.Variable.nonneg() for _ in range(nvars)]
+    objective = sum((float(c[j]) * xs[j] for j in range(1, nvars)), float(c[0]) * xs[0])
+    cons = []
+    for i in range(ncons):
+        cols = np.nonzero(a[i])[0]
+        if len(cols):
+            cons.append(sum((xs[j] * 1.0 for j in cols[1:]), xs[cols[0]] * 1.0) <= float(b[i]))
+    return dz.Maximize(objective).subject_to(cons)
+
+
+def _outcome(seed, numerics):
+    from dantzig_amd import _ffi
+
+    rs.set_options(numerics=numerics)
+    try:
+        return ("optimal", _zero_one_model(seed).solve().objective_value)
+    except Exception as exc:  # noqa: BLE001 -- the outcome IS the exception type and text
+        return (type(exc).__name__, str(exc))
+    finally:
+        rs.set_options()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 4, 5, 11])
+def test_auto_numerics_falls_back_to_strict_when_fast_gives_up(seed):
+    """Above auto_strict_rows AUTO runs FAST; when FAST stops with DZG_SINGULAR / DZG_PANIC,
+    Level 2 answers with the reference's own arithmetic (STRICT) instead of an error."""
+    from dantzig_amd import _ffi
+
+    fast = _outcome(seed, _ffi.FAST)
+    assert fast[0] == "RuntimeError" and "singular" in fast[1]
+    assert _outcome(seed, _ffi.AUTO) == _outcome(seed, _ffi.STRICT)
