@@ -228,6 +228,19 @@ def main() -> int:
     if args.gpus != world and world > 1:
         print(f"--gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
         return 2
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        # asked for several GPUs without a launcher: start one rank per GPU ourselves (this process
+        # has not touched the GPU yet) and pass the child's JSON line through
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+               str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        return subprocess.run(cmd).returncode
     if world > 1 or args.force_sharded:
         from dantzig_amd import sharded  # column-sharded path, native RCCL loop
 
