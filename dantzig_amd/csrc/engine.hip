@@ -968,7 +968,34 @@ extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result
     }
     int rc2 = dzg_solver_result(s, res);
     dzg_solver_destroy(s);
-    return rc2 != 0 ? rc2 : rc;
+    if (rc2 != 0) return rc2;
+    // AUTO numerics chose FAST and FAST lost its footing (DZG_SINGULAR: the basis inverse no longer
+    // agrees with itself; DZG_PANIC: a non-finite step length) -- degenerate or badly scaled data.
+    // Up to a size STRICT finishes in reasonable time, answer with the reference's own arithmetic:
+    // what the caller of Simplex::solve would have got.
+    const bool automatic = !opts || opts->numerics == DZG_NUMERICS_AUTO;
+    if (automatic && res->numerics_used == DZG_NUMERICS_FAST && lp->m <= 2048 &&
+        (rc == DZG_SINGULAR || rc == DZG_PANIC)) {
+        dzg_opts strict;
+        if (opts)
+            strict = *opts;
+        else
+            dzg_opts_default(&strict);
+        strict.numerics = DZG_NUMERICS_STRICT;
+        strict.refactor_interval = 0;
+        s = nullptr;
+        rc = dzg_solver_create(lp, &strict, &s);
+        if (rc != 0) return rc;
+        rc = dzg_solver_run(s, 0);
+        if (rc < 0) {
+            dzg_solver_destroy(s);
+            return rc;
+        }
+        rc2 = dzg_solver_result(s, res);
+        dzg_solver_destroy(s);
+        if (rc2 != 0) return rc2;
+    }
+    return rc;
 }
 
 // ---- single-function entry points for parity tests -------------------------------

@@ -271,26 +271,7 @@ extern "C" int dzg_model_solve(const dzg_model *md, const dzg_opts *opts, dzg_mo
     std::memset(&r, 0, sizeof(r));
     r.basis = basis.data();
     r.x = x.data();
-    int rc = dzg_core_solve(&lp, opts, &r);
-    // AUTO numerics chose FAST and FAST lost its footing (DZG_SINGULAR: the basis inverse no longer
-    // agrees with itself; DZG_PANIC: a non-finite step length): badly scaled or degenerate data.
-    // Answer with the reference's own arithmetic instead -- slower, but what the caller of
-    // dantzig.rust.solve would have got.
-    const bool automatic = !opts || opts->numerics == DZG_NUMERICS_AUTO;
-    if (rc >= 0 && automatic && r.numerics_used == DZG_NUMERICS_FAST &&
-        (r.status == DZG_SINGULAR || r.status == DZG_PANIC)) {
-        dzg_opts strict;
-        if (opts)
-            strict = *opts;
-        else
-            dzg_opts_default(&strict);
-        strict.numerics = DZG_NUMERICS_STRICT;
-        strict.refactor_interval = 0;
-        std::memset(&r, 0, sizeof(r));
-        r.basis = basis.data();
-        r.x = x.data();
-        rc = dzg_core_solve(&lp, &strict, &r);
-    }
+    const int rc = dzg_core_solve(&lp, opts, &r); // AUTO: falls back to STRICT if FAST gives up
     res->status = rc < 0 ? rc : r.status;
     res->numerics_used = r.numerics_used;
     res->iterations = r.iterations;

@@ -184,7 +184,9 @@ void dzg_solver_destroy(dzg_solver *s);
 /* FAST: rebuild the basis inverse from scratch now (needs opts.refactor_interval != 0 at
  * creation, which reserves the workspace). */
 int dzg_solver_refactor(dzg_solver *s);
-/* create + run + result + destroy */
+/* create + run + result + destroy.  With opts == NULL or numerics AUTO, a FAST run (more than
+ * auto_strict_rows rows) that ends in DZG_SINGULAR / DZG_PANIC is repeated with STRICT numerics --
+ * the reference's arithmetic -- for LPs of up to 2048 rows, and that result is returned. */
 int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res);
 
 /* ---- Level 2: replaces dantzig.rust.solve (src/lib.rs:16-27) ---------------------- */
@@ -217,8 +219,6 @@ typedef struct {
     int64_t m, n;         /* size of the standard form that was solved                  */
 } dzg_model_result;
 
-/* With opts == NULL or numerics AUTO: a FAST run that ends in DZG_SINGULAR / DZG_PANIC is repeated
- * with STRICT numerics (the reference's arithmetic) and that result is returned. */
 int dzg_model_solve(const dzg_model *model, const dzg_opts *opts, dzg_model_result *res);
 
 /* Host-only: the standard-form builder alone (Simplex::new, src/simplex.rs:123-224).
