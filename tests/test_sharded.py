@@ -212,3 +212,33 @@ def test_sharded_sparse_lockstep_matches_oracle():
     assert status == want.status
     for res in results:
         assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_whole_solve_follows_the_oracle_pivot_log(world):
+    """BASELINE config 2 (1024 x 2048) column-sharded over 4 / 8 ranks in lockstep on one GPU: every
+    rank takes the 21 642 pivots of the committed CPU-oracle log (tests/golden, 106 min of CPU) and
+    ends in its basis -- eta flushes, compact-column appends and deletes, ownership changes of
+    the pivot position and all."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_pivots_1002_1024x2048.npz"))
+    a, b, c = core.gen_dense_lp(seed=int(fx["seed"]), m=int(fx["m"]), n_struct=int(fx["n_struct"]))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    solvers = make_lockstep(lp, world, poll_interval=64)
+    try:
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == str(fx["status"]) == "optimal"
+    for res in results:
+        assert res.iterations == int(fx["iterations"])
+        assert np.array_equal(np.array([p[0] for p in res.pivots]), fx["kind"])
+        assert np.array_equal(np.array([p[1] for p in res.pivots]), fx["entering"])
+        assert np.array_equal(np.array([p[2] for p in res.pivots]), fx["leaving"])
+        assert np.array_equal(res.basis, fx["basis"])
+        assert abs(res.objective - float(fx["objective"])) <= 1e-9 * abs(float(fx["objective"]))
