@@ -559,3 +559,19 @@ def test_strict_follows_the_oracle_through_degenerate_lps(core):
         for name in ("x", "xbar", "z", "zbar"):
             assert _same_bits(getattr(got, name), getattr(want, name)), (case, name)
     assert {"optimal", "unbounded", "panic", "infeasible"} <= outcomes
+
+
+def test_whole_solve_from_csc_follows_the_oracle_pivot_log(core):
+    """The 512 x 1024 LP of the committed oracle log handed over as CSC (every entry stored): the
+    sparse device path -- CSC pricing in the reference's order, entering columns densified into
+    records -- takes the same 7 692 pivots."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_pivots_2001_512x1024.npz"))
+    m, ns = int(fx["m"]), int(fx["n_struct"])
+    a, b, c = core.gen_dense_lp(seed=int(fx["seed"]), m=m, n_struct=ns)
+    cp, ri, val = ora.csc_from_dense(np.asarray(a))
+    lp = core.CoreLP.from_csc(m, cp, ri, val, b, c)
+    got = core.solve(lp, numerics=core.FAST, poll_interval=64)
+    assert got.status == "optimal" and got.iterations == int(fx["iterations"])
+    assert np.array_equal(np.array([p[1] for p in got.pivots]), fx["entering"])
+    assert np.array_equal(np.array([p[2] for p in got.pivots]), fx["leaving"])
+    assert np.array_equal(got.basis, fx["basis"])
