@@ -87,7 +87,7 @@ int main(int argc, char **argv)
 #define SEQ2(CW, BLK) time_it("seq2<" #CW "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
     SEQ2(16, 256);
 #define SEQ2D(CW, DEP, DBG, NT, BLK) time_it("seq2<" #CW "," #DEP "," #DBG "," #NT "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW, DEP, DBG, NT>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
-    SEQ2D(16, 3, 0, true, 256); SEQ2D(16, 3, 1, true, 256); SEQ2D(8, 3, 0, true, 512); SEQ2D(8, 4, 0, true, 512); SEQ2D(16, 2, 0, true, 256); SEQ2D(16, 4, 0, true, 256); SEQ2D(32, 2, 0, true, 128);
+    SEQ2D(16, 3, 0, true, 256); SEQ2D(16, 3, 1, true, 256); SEQ2D(8, 3, 0, true, 512); SEQ2D(8, 4, 0, true, 512); SEQ2D(16, 2, 0, true, 256); SEQ2D(16, 4, 0, true, 256);
     {
         hipLaunchKernelGGL((k_price_seq2<16, 3, 4, true>), dim3(256), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr);
         CK(hipDeviceSynchronize());
