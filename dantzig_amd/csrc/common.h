@@ -103,10 +103,36 @@ __device__ __forceinline__ DzgCand dzg_block_best(DzgCand c)
     return o;
 }
 
+// IEEE-754 division, correctly rounded.  The compiler's fp64 division sequence for gfx950
+// (v_div_scale / v_rcp / Newton steps / v_div_fmas / v_div_fixup) is off by one unit in the last
+// place when the exact quotient lies within ~1e-32 (relative) of a rounding boundary -- e.g.
+// 1.3999999999999992 / -0.9999999999999994 -- which never shows on random data and does show on
+// "decimal" data (fuzz seed 2259, tools/fuzz_parity.py).  x86 (the reference's hardware) rounds
+// correctly, so every division a decision or a stored value depends on goes through here: the
+// residual of a quotient that is within an ulp is exact in one FMA, and so is the neighbour's;
+// the smaller residual is the nearer quotient.
+__device__ __forceinline__ double dzg_div(double a, double b)
+{
+    double q = a / b;
+    const double aa = fabs(a), ab = fabs(b), aq = fabs(q);
+    if (aa > 0x1p-900 && aa < 0x1p900 && ab > 0x1p-900 && ab < 0x1p900 && aq > 0x1p-900 &&
+        aq < 0x1p900) { // no overflow / underflow in the residuals
+        const double r = fma(-q, b, a);
+        if (r != 0.0) {
+            const bool towards_plus = (r > 0.0) == (b > 0.0); // the exact quotient is above q
+            const bool grow = towards_plus == (q > 0.0);      // its magnitude is larger than |q|
+            const double q2 = __longlong_as_double(__double_as_longlong(q) + (grow ? 1 : -1));
+            const double r2 = fma(-q2, b, a);
+            if (fabs(r2) < fabs(r)) q = q2;
+        }
+    }
+    return q;
+}
+
 // x / y with 0 / 0 = 0 (src/simplex.rs:464-468); *ok cleared on a non-finite result.
 __device__ __forceinline__ double dzg_safe_divide(double x, double y, int *ok)
 {
-    double d = (x == 0.0 && y == 0.0) ? 0.0 : x / y;
+    double d = (x == 0.0 && y == 0.0) ? 0.0 : dzg_div(x, y);
     if (isinf(d) || isnan(d)) *ok = 0;
     return d;
 }

@@ -328,7 +328,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
                 const double scaled = mu * xbar[i];
                 const double den = x[i] + scaled;
                 DzgCand cnd;
-                cnd.r = acc / den;
+                cnd.r = dzg_div(acc, den);
                 cnd.k = i;
                 if (cnd.r > 0.0) best = dzg_better(best, cnd);
             }
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
         }
         if (xb > 0.0) {
             DzgCand c;
-            c.r = -xi / xb;
+            c.r = dzg_div(-xi, xb);
             c.k = i;
             if (c.r == c.r) bx = dzg_better(bx, c);
         }
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
         }
         if (mine && zb > 0.0) {
             DzgCand c;
-            c.r = -zk / zb;
+            c.r = dzg_div(-zk, zb);
             c.k = k;
             if (c.r == c.r) bz = dzg_better(bz, c);
         }

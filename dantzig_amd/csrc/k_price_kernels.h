@@ -44,7 +44,7 @@ __device__ __forceinline__ void price_candidate(DzgCand &best, double dzk, int p
     const double scaled = mu * zbar[pos];
     const double den = z[pos] + scaled;
     DzgCand c;
-    c.r = dzk / den;
+    c.r = dzg_div(dzk, den);
     c.k = pos;
     if (c.r > 0.0) best = dzg_better(best, c);
 }

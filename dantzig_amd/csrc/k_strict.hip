@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_lu_step(const DzgCtl *ctl, int n, int k
         const double s_k = dzg_readlane_f64(s_c, ck);
         // zero pivot: no scaling, no update of the matrix (src/linalg.rs:117-125); LU::solve
         // still runs b[i] -= b[k] * a(i,k) with the stored entry (src/linalg.rs:288-290)
-        const double l = zero ? s_k : s_k / pivot;
+        const double l = zero ? s_k : dzg_div(s_k, pivot);
         double val = s_c;
         if (!zero) {
             const double adjustment = l * u_c;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(1024) void k_lu_panel_lds(const DzgCtl *ctl, int n,
             const double s_k = row[s];
             // zero pivot: no scaling, no update of the matrix (src/linalg.rs:117-125); LU::solve
             // still runs b[i] -= b[k] * a(i,k) with the stored entry (src/linalg.rs:288-290)
-            const double l = zero ? s_k : s_k / pivot;
+            const double l = zero ? s_k : dzg_div(s_k, pivot);
             if (!zero && lane > s && lane < nbw) {
                 const double adjustment = l * u_c;
                 row[lane] = row[lane] - adjustment;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void k_lu_backsolve(const DzgCtl *ctl, int n,
             buf ^= 1;
             cj += 64;
             if (alive && cj >= n) { // row finished
-                acc = acc / diag;
+                acc = dzg_div(acc, diag);
                 if (lane == 0) B_SET(ci, acc);
                 if (!LDS_B) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();

@@ -23,7 +23,7 @@ __device__ __forceinline__ DzgCand scan_first(const double *__restrict__ y,
         double yb = ybar[k];
         if (yb > 0.0) {
             DzgCand c;
-            c.r = -y[k] / yb;
+            c.r = dzg_div(-y[k], yb);
             c.k = k;
             if (c.r == c.r) best = dzg_better(best, c);
         }
@@ -43,7 +43,7 @@ __device__ __forceinline__ DzgCand scan_second(double mu, const double *__restri
         double scaled = mu * ybar[k];
         double den = y[k] + scaled;
         DzgCand c;
-        c.r = dy[k] / den;
+        c.r = dzg_div(dy[k], den);
         c.k = k;
         if (c.r > 0.0) best = dzg_better(best, c);
     }

@@ -45,6 +45,21 @@ def test_lu_solve_bit_exact(core, n):
     assert_bit_equal(x, ora.lu_solve(a, b), "x")
 
 
+def test_division_is_correctly_rounded(core):
+    """IEEE-754 division as x86 (the reference) does it: the compiler's fp64 sequence for gfx950
+    is one unit off on quotients within ~1e-32 of a rounding boundary; dzg_div repairs it.
+    A 1 x 1 system is one division (src/linalg.rs:297)."""
+    rng = np.random.default_rng(1)
+    cases = [(1.3999999999999992, -0.9999999999999994), (2.849572429871236e-14, 1.5543122344752195e-14),
+             (11.0, 6.0), (1.0, 3.0), (-7.0, 5.0), (1e300, 1e-5), (1e-300, 1e5), (0.0, 2.0)]
+    cases += [(float(n) / 10.0, float(d) / 10.0) for n in range(1, 40) for d in (3, 7, 9, 10, 11, 13)]
+    cases += [(float(x), float(y)) for x, y in zip(rng.uniform(-2, 2, 200), rng.uniform(0.5, 2, 200))]
+    for num, den in cases:
+        x, _, _ = core.lu_solve(np.array([[den]]), np.array([num]))
+        want = np.float64(num) / np.float64(den)
+        assert _bits(x)[0] == _bits(np.array([want]))[0], (num, den, float(x[0]), float(want))
+
+
 def test_lu_kats_on_gpu(core, kats):
     k = kats["linalg"]["lu_factorization"]
     _, lu, p = core.lu_solve(np.array(k["a"]), np.ones(3))
@@ -523,13 +538,14 @@ def test_whole_solve_follows_the_oracle_pivot_log(core, path):
 
 
 # ------------------------------------------------------------------ degenerate / integer LPs
-def _fuzz_lp(core, case):
+def _fuzz_lp(core, case, kind=None):
     rng = np.random.default_rng(case)
     m, ns = int(rng.integers(1, 70)), int(rng.integers(1, 140))
-    if case % 3 == 0:
+    kind = case % 3 if kind is None else kind
+    if kind == 0:
         a, b, c = core.gen_dense_lp(seed=case, m=m, n_struct=ns)
         return np.array(a), b, c
-    if case % 3 == 1:  # small integers, many zeros: exact ties in both pivot rules
+    if kind == 1:  # small integers, many zeros: exact ties in both pivot rules
         return (rng.integers(-3, 4, (m, ns)).astype(np.float64),
                 rng.integers(-2, 9, m).astype(np.float64), rng.integers(-4, 5, ns).astype(np.float64))
     return ((rng.uniform(size=(m, ns)) < 0.3).astype(np.float64),  # 0/1 matrix: degenerate vertices
@@ -548,8 +564,10 @@ def test_strict_follows_the_oracle_through_degenerate_lps(core):
     "unbounded" verdicts -- tools/fuzz_parity.py).  STRICT must go wherever the reference goes:
     same status, same pivots, same mu and the same vectors bit for bit, NaNs in the same places."""
     outcomes = set()
-    for case in range(90):
-        a, b, c = _fuzz_lp(core, case)
+    # 2259 (as a 0/1 LP): the solve hits 1.3999999999999992 / -0.9999999999999994, a quotient so
+    # close to a rounding boundary that the stock fp64 division sequence of gfx950 misses it
+    for case, kind in [(c, None) for c in range(90)] + [(2259, 2)]:
+        a, b, c = _fuzz_lp(core, case, kind)
         want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=5000)
         got = core.solve(core.CoreLP.from_inequality_form(a, b, c), numerics=core.STRICT, max_iter=5000)
         outcomes.add(want.status)
