@@ -8,17 +8,22 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------
-// find_first_pivot over one side: argmax_k -y_k / ybar_k over ybar_k > 0.
-// Deviation (documented in DESIGN.md): a NaN ratio is never selected; the reference's
-// sequential fold would get stuck on a NaN first element, a state it can only reach
-// after its own safe_divide assert has already fired.
+// find_first_pivot over one side: argmax_k -y_k / ybar_k over ybar_k > 0, as the reference's
+// sequential reduce (src/simplex.rs:423-437): the accumulator starts as the FIRST surviving
+// element and is replaced only by a strictly larger ratio.  Two consequences: ties go to the
+// lowest k, and a NaN ratio on the first surviving element sticks (nothing is > NaN), while a
+// NaN further down is skipped.  The reference does reach such states (x = -inf, xbar = +inf
+// after a solve through a singular basis: fuzz seed 4251) and its verdict there -- a dual step
+// with mu = NaN, hence "infeasible" -- is reproduced.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ DzgCand scan_first(const double *__restrict__ y,
                                               const double *__restrict__ ybar, int len)
 {
-    DzgCand best;
+    DzgCand best, first;
     best.r = 0.0;
     best.k = -1;
+    first.r = 0.0;
+    first.k = -1;
     for (int k = threadIdx.x; k < len; k += blockDim.x) {
         double yb = ybar[k];
         if (yb > 0.0) {
@@ -26,9 +31,22 @@ __device__ __forceinline__ DzgCand scan_first(const double *__restrict__ y,
             c.r = dzg_div(-y[k], yb);
             c.k = k;
             if (c.r == c.r) best = dzg_better(best, c);
+            if (first.k < 0) { // this thread's lowest surviving k; max of -k = min of k
+                first.r = -(double)k;
+                first.k = k;
+            }
         }
     }
-    return dzg_block_best(best);
+    first = dzg_block_best(first);
+    best = dzg_block_best(best);
+    if (first.k >= 0) {
+        const double r0 = dzg_div(-y[first.k], ybar[first.k]);
+        if (r0 != r0) { // the fold starts on a NaN and never leaves it
+            best.r = r0;
+            best.k = first.k;
+        }
+    }
+    return best;
 }
 
 // find_second_pivot: argmax_k dy_k / (y_k + mu*ybar_k) over ratios > 0 (+inf included).

@@ -172,6 +172,16 @@ def test_first_and_second_pivot_match_oracle(core):
             assert core.second_pivot(mu, y, ybar, dy) == ora.find_second_pivot(mu, y, ybar, dy)
     assert core.first_pivot(np.array([1.0]), np.array([0.0])) == -1
     assert core.second_pivot(1.0, np.array([-1.0]), np.ones(1), np.array([0.0])) == -1
+    # the reference's reduce starts on the first surviving element: a NaN ratio there sticks
+    # (nothing is > NaN), a NaN further down is skipped (src/simplex.rs:432-435)
+    inf, nan = float("inf"), float("nan")
+    for y, ybar in [([-inf, -3.0, -5.0], [inf, 1.0, 1.0]),      # inf/inf first: sticks at 0
+                    ([-1.0, -inf, -5.0], [1.0, inf, 1.0]),       # NaN in the middle: skipped
+                    ([2.0, nan, -1.0], [0.0, 1.0, 1.0]),         # first SURVIVING element is the NaN
+                    ([nan] + [-float(k) for k in range(2000)], [1.0] * 2001),
+                    ([-float(k) for k in range(2000)] + [nan], [1.0] * 2001)]:
+        y, ybar = np.array(y), np.array(ybar)
+        assert core.first_pivot(y, ybar) == ora.find_first_pivot(y, ybar)
 
 
 # ------------------------------------------------------------------ whole solves
@@ -566,7 +576,9 @@ def test_strict_follows_the_oracle_through_degenerate_lps(core):
     outcomes = set()
     # 2259 (as a 0/1 LP): the solve hits 1.3999999999999992 / -0.9999999999999994, a quotient so
     # close to a rounding boundary that the stock fp64 division sequence of gfx950 misses it
-    for case, kind in [(c, None) for c in range(90)] + [(2259, 2)]:
+    # 4251 (as a 0/1 LP): a solve through a singular basis leaves x = -inf, xbar = +inf, the first
+    # pivot rule starts on inf/inf = NaN and the reference ends in a dual step with mu = NaN
+    for case, kind in [(c, None) for c in range(90)] + [(2259, 2), (4251, 2)]:
         a, b, c = _fuzz_lp(core, case, kind)
         want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=5000)
         got = core.solve(core.CoreLP.from_inequality_form(a, b, c), numerics=core.STRICT, max_iter=5000)
