@@ -117,13 +117,16 @@ __device__ __forceinline__ double dzg_div(double a, double b)
     const double aa = fabs(a), ab = fabs(b), aq = fabs(q);
     if (aa > 0x1p-900 && aa < 0x1p900 && ab > 0x1p-900 && ab < 0x1p900 && aq > 0x1p-900 &&
         aq < 0x1p900) { // no overflow / underflow in the residuals
-        const double r = fma(-q, b, a);
-        if (r != 0.0) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) { // one step repairs an error of one ulp; two, of two
+            const double r = fma(-q, b, a);
+            if (r == 0.0) break;
             const bool towards_plus = (r > 0.0) == (b > 0.0); // the exact quotient is above q
             const bool grow = towards_plus == (q > 0.0);      // its magnitude is larger than |q|
             const double q2 = __longlong_as_double(__double_as_longlong(q) + (grow ? 1 : -1));
             const double r2 = fma(-q2, b, a);
-            if (fabs(r2) < fabs(r)) q = q2;
+            if (!(fabs(r2) < fabs(r))) break;
+            q = q2;
         }
     }
     return q;
