@@ -134,3 +134,28 @@ def test_zero_pivot_column_is_skipped():
     lu, p = ora.lu_factorize(a)
     assert p.tolist() == [0]
     assert lu.tolist() == a.tolist()
+
+
+def test_optimality_certificate_agrees_with_the_oracle():
+    """tests/optimality.py (the LAPACK duality check the GPU suite relies on at sizes the oracle
+    cannot reach) on LPs the oracle does solve: its optimal bases must pass, a non-optimal basis
+    must not."""
+    import numpy as np
+
+    from dantzig_amd import core  # host-side generator only
+    from oracle import oracle as ora
+    from tests.optimality import certificate
+
+    for seed, m, ns in [(3, 12, 30), (4, 40, 25), (5, 33, 33)]:
+        a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+        a = np.asarray(a)
+        res = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+        assert res.status == "optimal"
+        cert = certificate(a, b, c, res.basis)
+        scale = max(1.0, abs(res.objective))
+        assert cert["primal_infeas"] <= 1e-9 and cert["dual_infeas"] <= 1e-9
+        assert abs(cert["primal_obj"] - cert["dual_obj"]) <= 1e-9 * scale
+        assert abs(cert["primal_obj"] - res.objective) <= 1e-9 * scale
+        early = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=max(1, res.iterations // 2))
+        bad = certificate(a, b, c, early.basis)
+        assert bad["primal_infeas"] > 1e-9 or bad["dual_infeas"] > 1e-9
