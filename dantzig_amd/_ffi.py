@@ -15,11 +15,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdantzig_amd.so")
 
 # dzg_status
-OPTIMAL, UNBOUNDED, INFEASIBLE, ITER_LIMIT, SINGULAR, PANIC, RUNNING = range(7)
+OPTIMAL, UNBOUNDED, INFEASIBLE, ITER_LIMIT, SINGULAR, PANIC, RUNNING, NEAR_TIE = range(8)
 E_DEVICE, E_ARG, E_NOMEM = -1, -2, -3
 STRICT, FAST, AUTO = 0, 1, 2
 PRICE_AUTO, PRICE_SEQ, PRICE_WAVE = 0, 1, 2
 STEP_PRIMAL, STEP_DUAL = 0, 1
+NEAR_TIE_COUNT, NEAR_TIE_STOP = 0, 1
 K_STATUS, K_FTRAN, K_RATIO, K_BTRAN, K_PRICE, K_UPDATE, K_BASIS_UPDATE, K_LU, K_COUNT = range(9)
 KERNEL_CLASSES = ["status", "ftran", "ratio", "btran", "price", "update", "basis_update", "lu"]
 
@@ -53,7 +54,7 @@ class Opts(C.Structure):
         ("log_capacity", C.c_int64), ("poll_interval", C.c_int32), ("profile", C.c_int32),
         ("col_begin", C.c_int64), ("col_end", C.c_int64), ("rank", C.c_int32),
         ("world", C.c_int32), ("stream", C.c_void_p), ("refactor_interval", C.c_int64),
-        ("a_is_block", C.c_int32), ("reserved0", C.c_int32),
+        ("a_is_block", C.c_int32), ("near_tie_action", C.c_int32), ("tie_tol", C.c_double),
     ]
 
 
@@ -70,6 +71,8 @@ class Result(C.Structure):
         ("z", C.c_void_p), ("zbar", C.c_void_p), ("log", C.c_void_p), ("log_cap", C.c_int64),
         ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_int64 * K_COUNT),
         ("price_bytes", C.c_double), ("solve_ms", C.c_double), ("max_pivot_error", C.c_double),
+        ("near_ties", C.c_int64), ("first_near_tie", C.c_int64), ("min_margin", C.c_double),
+        ("margins", C.c_void_p), ("dense_columns", C.c_int64), ("refactors", C.c_int64),
     ]
 
 
@@ -87,7 +90,7 @@ class Model(C.Structure):
 class ModelResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("numerics_used", C.c_int32), ("iterations", C.c_int64),
                 ("objective", C.c_double), ("values", C.c_void_p), ("m", C.c_int64),
-                ("n", C.c_int64)]
+                ("n", C.c_int64), ("near_ties", C.c_int64), ("first_near_tie", C.c_int64)]
 
 
 class StdForm(C.Structure):

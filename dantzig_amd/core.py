@@ -13,10 +13,10 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import (AUTO, FAST, STRICT, PRICE_AUTO, PRICE_SEQ, PRICE_WAVE, STEP_DUAL,  # noqa: F401
-                   STEP_PRIMAL, DantzigAmdError, f64, i64, ptr)
+                   STEP_PRIMAL, NEAR_TIE_COUNT, NEAR_TIE_STOP, DantzigAmdError, f64, i64, ptr)
 
 STATUS_NAMES = {0: "optimal", 1: "unbounded", 2: "infeasible", 3: "iter_limit", 4: "singular",
-                5: "panic", 6: "running"}
+                5: "panic", 6: "running", 7: "near_tie"}
 
 
 @dataclass
@@ -108,12 +108,27 @@ class CoreResult:
     price_bytes: float = 0.0
     solve_ms: float = 0.0
     max_pivot_error: float = 0.0
+    # FAST near-tie arbitration: the pivot log is certified to be the reference's up to (not
+    # including) pivot first_near_tie; near_ties == 0: all of it
+    near_ties: int = 0
+    first_near_tie: int = -1
+    min_margin: float = float("inf")
+    margins: np.ndarray | None = None   # per-pivot smallest decision margin (log=True)
+    dense_columns: int = 0              # k: structural basics = dense columns of the inverse
+    refactors: int = 0
 
 
 class Solver:
     """One LP resident on one GPU.  create -> run (repeatable, budgeted) -> result."""
 
     def __init__(self, lp: CoreLP, **opts):
+        self._prepare(lp, opts)
+        rc = _ffi.lib().dzg_solver_create(C.byref(self._c_lp), C.byref(self._opts),
+                                          C.byref(self._h))
+        _ffi.check(rc, "dzg_solver_create")
+
+    def _prepare(self, lp: CoreLP, opts: dict) -> "Solver":
+        """Marshals the LP and the options into their C structs (no device work)."""
         _ffi.require_gpu()
         self._lp = lp
         m, ns, n = lp.m, lp.n_struct, lp.n
@@ -140,9 +155,7 @@ class Solver:
             opts["a_is_block"] = 1
         self._opts = _ffi.default_opts(**opts)
         self._h = C.c_void_p(None)
-        rc = _ffi.lib().dzg_solver_create(C.byref(self._c_lp), C.byref(self._opts),
-                                          C.byref(self._h))
-        _ffi.check(rc, "dzg_solver_create")
+        return self
 
     def run(self, max_new_iters: int = 0) -> str:
         rc = _ffi.lib().dzg_solver_run(self._h, int(max_new_iters))
@@ -161,11 +174,12 @@ class Solver:
         r.z, r.zbar = ptr(z), ptr(zbar)
         r.log, r.log_cap = None, 0
         _ffi.check(_ffi.lib().dzg_solver_result(self._h, C.byref(r)), "dzg_solver_result")
-        pivots = []
+        pivots, margins = [], None
         if log and r.iterations > 0:
             cnt = int(min(r.iterations, cap))
             buf = (_ffi.Pivot * cnt)()
-            r.log, r.log_cap = C.cast(buf, C.c_void_p), cnt
+            margins = np.full(cnt, np.inf)
+            r.log, r.log_cap, r.margins = C.cast(buf, C.c_void_p), cnt, ptr(margins)
             _ffi.check(_ffi.lib().dzg_solver_result(self._h, C.byref(r)), "dzg_solver_result")
             arr = np.ctypeslib.as_array(buf)
             pivots = list(zip(arr["kind"].tolist(), arr["entering"].tolist(),
@@ -179,7 +193,9 @@ class Solver:
             kernel_ms={k: r.kernel_ms[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
             kernel_launches={k: r.kernel_launches[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
             price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms),
-            max_pivot_error=float(r.max_pivot_error))
+            max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
+            first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin), margins=margins,
+            dense_columns=int(r.dense_columns), refactors=int(r.refactors))
 
     def refactor(self) -> None:
         """FAST: rebuild the basis inverse from scratch now (blocked LU + MFMA GEMMs)."""
@@ -208,6 +224,38 @@ def solve(lp: CoreLP, log: bool = True, **opts) -> CoreResult:
     with Solver(lp, **opts) as s:
         s.run(0)
         return s.result(log=log)
+
+
+def core_solve(lp: CoreLP, log_cap: int = 1 << 20, **opts) -> CoreResult:
+    """dzg_core_solve: one call, with the AUTO policy of the C ABI (FAST that stops at the first
+    near tie and is then re-solved in STRICT, up to DZG_AUTO_STRICT_RESTART_ROWS rows)."""
+    with Solver.__new__(Solver)._prepare(lp, opts) as s:
+        m, q = lp.m, lp.n - lp.m
+        basis, nonbasis = np.zeros(max(m, 1), np.int64), np.zeros(max(q, 1), np.int64)
+        x, xbar = np.zeros(max(m, 1)), np.zeros(max(m, 1))
+        z, zbar = np.zeros(max(q, 1)), np.zeros(max(q, 1))
+        buf = (_ffi.Pivot * max(log_cap, 1))()
+        margins = np.full(max(log_cap, 1), np.inf)
+        r = _ffi.Result()
+        r.basis, r.nonbasis, r.x, r.xbar = ptr(basis), ptr(nonbasis), ptr(x), ptr(xbar)
+        r.z, r.zbar = ptr(z), ptr(zbar)
+        r.log, r.log_cap, r.margins = C.cast(buf, C.c_void_p), log_cap, ptr(margins)
+        rc = _ffi.lib().dzg_core_solve(C.byref(s._c_lp), C.byref(s._opts), C.byref(r))
+        _ffi.check(rc, "dzg_core_solve")
+        cnt = int(min(r.iterations, log_cap))
+        arr = np.ctypeslib.as_array(buf)[:cnt]
+        pivots = list(zip(arr["kind"].tolist(), arr["entering"].tolist(),
+                          arr["leaving"].tolist(), arr["mu"].tolist()))
+        return CoreResult(
+            status=STATUS_NAMES.get(r.status, str(r.status)), status_code=r.status,
+            numerics="strict" if r.numerics_used == STRICT else "fast",
+            iterations=int(r.iterations), objective=float(r.objective),
+            basis=basis[:m].copy(), nonbasis=nonbasis[:q].copy(), x=x[:m].copy(),
+            xbar=xbar[:m].copy(), z=z[:q].copy(), zbar=zbar[:q].copy(), pivots=pivots,
+            max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
+            first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin),
+            margins=margins[:cnt].copy(), dense_columns=int(r.dense_columns),
+            refactors=int(r.refactors))
 
 
 # ------------------------------------------------------------------ synthetic LPs (SURVEY 8(d))

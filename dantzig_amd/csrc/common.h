@@ -42,7 +42,20 @@ struct DzgCtl {
     int del_ce;          //       slack): column del_ce := column del_last, column del_last := 0
     int pad2;
     long long nb_nnz;     // sparse mode: stored entries of the owned nonbasic structural columns
-    double max_pivot_err; // FAST health: max |dx_p + dz_r| / max(|dx_p|, |dz_r|) over all pivots
+    double max_pivot_err; // FAST health: max |dx_p + dz_r| / max(|dx_p|, |dz_r|) since the last
+                          // refactorisation
+    // FAST near-tie arbitration (see DzgCand2): every argmax of the pivot rule carries its
+    // runner-up; a decision whose margin is within `tau` of a tie is one the reference's
+    // arithmetic may take the other way.
+    double tie_tol;       // opts.tie_tol
+    double tau;           // effective tolerance = max(tie_tol, 64 * max_pivot_err)
+    double margin;        // smallest relative margin among the decisions of the pivot in flight
+    double min_margin;    // ... over all executed pivots
+    long long near_ties;  // pivots with at least one decision inside tau
+    long long first_near_tie; // iteration index of the first of them, -1: none
+    long long tie_skip_iter;  // stop mode: the iteration the host has acknowledged (resume)
+    int tie_mode;         // 0: count and carry on, 1: stop with DZG_NEAR_TIE before the pivot
+    int tie_seen;         // a decision of the pivot in flight was inside tau
 };
 
 // Partial-reduction fan-in sizes of the FAST pipeline (fixed grids => fixed counts)
@@ -57,7 +70,95 @@ struct DzgCand {
     int k;
 };
 
+// FAST numerics: argmax candidate that also carries its competition.  `h` is the largest
+// ratio among all OTHER candidates that took part (the runner-up), -inf when there was none,
+// +inf when some candidate's ratio cannot be trusted at all (a denominator that is zero up to
+// rounding: the reference may have +-inf, NaN or an excluded candidate there).
+struct DzgCand2 {
+    double r;
+    int k;
+    double h;
+};
+
 #ifdef __HIPCC__
+
+__device__ __forceinline__ DzgCand2 dzg_cand2_none()
+{
+    DzgCand2 c;
+    c.r = 0.0;
+    c.k = -1;
+    c.h = -__builtin_inf();
+    return c;
+}
+
+// Same winner as dzg_better; the loser's ratio joins the competition record.
+__device__ __forceinline__ DzgCand2 dzg_better2(DzgCand2 a, DzgCand2 b)
+{
+    const bool b_wins = a.k < 0 ? true : (b.k < 0 ? false : (b.r > a.r || (b.r == a.r && b.k < a.k)));
+    DzgCand2 w = b_wins ? b : a;
+    const DzgCand2 l = b_wins ? a : b;
+    double h = a.h > b.h ? a.h : b.h;
+    if (l.k >= 0 && l.r > h) h = l.r;
+    w.h = h;
+    return w;
+}
+
+__device__ __forceinline__ DzgCand2 dzg_wave_best2(DzgCand2 c)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        DzgCand2 o;
+        o.r = __shfl_xor(c.r, off, DZG_WAVE);
+        o.k = __shfl_xor(c.k, off, DZG_WAVE);
+        o.h = __shfl_xor(c.h, off, DZG_WAVE);
+        c = dzg_better2(c, o);
+    }
+    return c;
+}
+
+// Block-wide reduction; result valid in every thread.  blockDim.x <= 1024.
+__device__ __forceinline__ DzgCand2 dzg_block_best2(DzgCand2 c)
+{
+    __shared__ double s2_r[16], s2_h[16];
+    __shared__ int s2_k[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    c = dzg_wave_best2(c);
+    __syncthreads(); // protect the arrays from a previous use
+    if (lane == 0) {
+        s2_r[wave] = c.r;
+        s2_k[wave] = c.k;
+        s2_h[wave] = c.h;
+    }
+    __syncthreads();
+    DzgCand2 o = dzg_cand2_none();
+    if (lane < nw) {
+        o.r = s2_r[lane];
+        o.k = s2_k[lane];
+        o.h = s2_h[lane];
+    }
+    return dzg_wave_best2(o);
+}
+
+// Relative margin of a decision: (winner - runner-up) / max(|winner|, |runner-up|).
+// +inf: no competition; 0: exact tie; -1: the decision rests on an untrustworthy ratio.
+__device__ __forceinline__ double dzg_margin(DzgCand2 c)
+{
+    const double inf = __builtin_inf();
+    if (c.h == inf) return -1.0;
+    if (c.k < 0 || c.h == -inf) return inf;
+    const double a = fabs(c.r), b = fabs(c.h);
+    const double den = a > b ? a : b;
+    if (!(den > 0.0)) return 0.0;
+    if (den == inf) return c.r == c.h ? 0.0 : inf; // +inf ratios are legitimate
+    return (c.r - c.h) / den;
+}
+
+// A zero that is only zero up to rounding: |d| <= tau * (|a| + |b| + 1) for d = a + b.
+__device__ __forceinline__ bool dzg_noise_zero(double d, double a, double b, double tau)
+{
+    return fabs(d) <= tau * (fabs(a) + fabs(b) + 1.0);
+}
 
 __device__ __forceinline__ DzgCand dzg_better(DzgCand a, DzgCand b)
 {
@@ -207,6 +308,8 @@ struct DzgDev {
     int *pslot;        // [q] index into plist or -1
     double *fpx_r, *fpz_r, *rx_r, *rz_r; // partial candidates (ratios)
     int *fpx_k, *fpz_k, *rx_k, *rz_k;    // partial candidates (positions)
+    double *fpx_h, *fpz_h, *rx_h, *rz_h; // partial candidates (runner-up ratios, DzgCand2::h)
+    double *log_margin;                  // [log_cap] smallest decision margin of each pivot
     // strict numerics
     DzgLu lu;
     double eps;

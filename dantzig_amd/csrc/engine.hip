@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,7 @@ extern "C" const char *dzg_status_str(int s)
     case DZG_SINGULAR: return "singular";
     case DZG_PANIC: return "panic";
     case DZG_RUNNING: return "running";
+    case DZG_NEAR_TIE: return "near_tie";
     case DZG_E_DEVICE: return "device_error";
     case DZG_E_ARG: return "bad_argument";
     case DZG_E_NOMEM: return "out_of_memory";
@@ -73,6 +75,8 @@ extern "C" void dzg_opts_default(dzg_opts *o)
     o->poll_interval = 32;
     o->profile = 0;
     o->world = 1;
+    o->near_tie_action = DZG_NEAR_TIE_COUNT;
+    o->tie_tol = 1e-11;
 }
 
 struct dzg_solver {
@@ -98,6 +102,10 @@ struct dzg_solver {
     bool graphs_tried = false;
     int prof_slot = -1; // phase path: event slot of the iteration being enqueued (-1: none)
     int64_t refactors = 0;
+    double drift_trigger = 1e-9; // FAST health: disagreement of the two pivot elements that
+                                 // triggers a refactorisation
+    double max_err_life = 0.0; // largest ctl->max_pivot_err ever read (the device value restarts
+                               // at every refactorisation)
     // column sharding
     void *comm = nullptr;                  // ncclComm_t
     double *xsend = nullptr, *xrecv1 = nullptr, *xrecv2 = nullptr;
@@ -200,6 +208,7 @@ const int kNcclFloat64 = 8;
 static void shard_comm_destroy(dzg_solver *s);
 static int shard_buffers(dzg_solver *s);
 static int refactor_now(dzg_solver *s);
+static int refactor_workspace(dzg_solver *s);
 
 extern "C" void dzg_solver_destroy(dzg_solver *s)
 {
@@ -226,6 +235,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     if (o.poll_interval <= 0) o.poll_interval = 32;
     if (o.epsilon == 0.0) o.epsilon = 1e-12;
     if (o.auto_strict_rows <= 0) o.auto_strict_rows = 192;
+    if (o.tie_tol == 0.0) o.tie_tol = 1e-11;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -368,6 +378,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     d.log_cap = cap;
     TRY(dev_alloc(s, &d.log_kind, (size_t)cap)); TRY(dev_alloc(s, &d.log_enter, (size_t)cap));
     TRY(dev_alloc(s, &d.log_leave, (size_t)cap)); TRY(dev_alloc(s, &d.log_mu, (size_t)cap));
+    TRY(dev_alloc(s, &d.log_margin, (size_t)cap));
 
     // --- numerics
     s->numerics = o.numerics == DZG_NUMERICS_AUTO
@@ -385,6 +396,10 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     c0.enter_pos = c0.leave_pos = -1;
     c0.del_ce = c0.del_last = -1;
     c0.nb_struct = nb_struct;
+    c0.tie_tol = c0.tau = o.tie_tol;
+    c0.margin = c0.min_margin = std::numeric_limits<double>::infinity();
+    c0.first_near_tie = c0.tie_skip_iter = -1;
+    c0.tie_mode = o.near_tie_action == DZG_NEAR_TIE_STOP ? 1 : 0;
     HIP_OK(hipMemcpyAsync(d.ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, s->st));
     *s->h_ctl = c0;
 
@@ -418,18 +433,9 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));
         TRY(dev_alloc(s, &d.fpx_k, np)); TRY(dev_alloc(s, &d.fpz_k, np));
         TRY(dev_alloc(s, &d.rx_k, np)); TRY(dev_alloc(s, &d.rz_k, np));
-        if (o.refactor_interval != 0 && d.world > 1)
-            return fail(DZG_E_ARG, "refactorisation needs every basic column on the device: not "
-                                   "available for a column-sharded solver");
-        if (o.refactor_interval != 0) {
-            s->rf_ld = ((long long)m + 15) / 16 * 16 + 16;
-            TRY(dev_alloc(s, &s->rfG, (size_t)(m ? m : 1) * (size_t)s->rf_ld));
-            TRY(dev_alloc(s, &s->rfX, (size_t)(m ? m : 1) * (size_t)s->rf_ld));
-            TRY(dev_alloc(s, &s->rf_piv, (size_t)m)); TRY(dev_alloc(s, &s->rf_spos, (size_t)m));
-            TRY(dev_alloc(s, &s->rf_scode, (size_t)m)); TRY(dev_alloc(s, &s->rf_lpos, (size_t)m));
-            TRY(dev_alloc(s, &s->rf_lrow, (size_t)m)); TRY(dev_alloc(s, &s->rf_counts, 4));
-            TRY(dev_alloc(s, &s->rf_lslot, (size_t)(m ? m : 1)));
-        }
+        TRY(dev_alloc(s, &d.fpx_h, np)); TRY(dev_alloc(s, &d.fpz_h, np));
+        TRY(dev_alloc(s, &d.rx_h, np)); TRY(dev_alloc(s, &d.rz_h, np));
+        if (o.refactor_interval != 0) TRY(refactor_workspace(s));
         dzg_launch_fast_init(d, s->st);
         dzg_launch_fast_update(d, 1, s->st); // first-pivot partials of the initial state
         if (needs_initial_refactor) {
@@ -544,20 +550,45 @@ static int read_ctl(dzg_solver *s)
 {
     HIP_OK(hipMemcpyAsync(s->h_ctl, s->d.ctl, sizeof(DzgCtl), hipMemcpyDeviceToHost, s->st));
     HIP_OK(hipStreamSynchronize(s->st));
+    if (s->h_ctl->max_pivot_err > s->max_err_life) s->max_err_life = s->h_ctl->max_pivot_err;
     return 0;
 }
 
 // Rebuild Binv0 from scratch for the current basis (k_refactor.hip).  One host sync to learn
 // k; everything else is enqueued.
+// The refactorisation workspace (two m x m panels and a few index lists) is reserved when the
+// options ask for periodic refactorisation, and otherwise on first need: a solver that never
+// drifts never pays for it, and one that does can still recover.
+static int refactor_workspace(dzg_solver *s)
+{
+    if (s->rfG) return 0;
+    if (s->d.world > 1)
+        return fail(DZG_E_ARG, "refactorisation needs every basic column on the device: not "
+                               "available for a column-sharded solver");
+    const size_t m = (size_t)(s->d.m ? s->d.m : 1);
+    s->rf_ld = ((long long)s->d.m + 15) / 16 * 16 + 16;
+    double *g = nullptr;
+    TRY(dev_alloc(s, &g, m * (size_t)s->rf_ld));
+    TRY(dev_alloc(s, &s->rfX, m * (size_t)s->rf_ld));
+    TRY(dev_alloc(s, &s->rf_piv, m)); TRY(dev_alloc(s, &s->rf_spos, m));
+    TRY(dev_alloc(s, &s->rf_scode, m)); TRY(dev_alloc(s, &s->rf_lpos, m));
+    TRY(dev_alloc(s, &s->rf_lrow, m)); TRY(dev_alloc(s, &s->rf_counts, 4));
+    TRY(dev_alloc(s, &s->rf_lslot, m));
+    s->rfG = g; // set last: rfG != nullptr means "workspace complete"
+    return 0;
+}
+
 static int refactor_now(dzg_solver *s)
 {
-    if (!s->rfG) return fail(DZG_E_ARG, "refactor workspace not reserved (opts.refactor_interval)");
+    TRY(refactor_workspace(s));
     const DzgDev &d = s->d;
     dzg_launch_refactor_lists(d, s->rf_spos, s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_counts, s->st);
     int counts[2] = {0, 0};
     HIP_OK(hipMemcpyAsync(counts, s->rf_counts, sizeof(counts), hipMemcpyDeviceToHost, s->st));
     TRY(read_ctl(s));
-    if (s->h_ctl->status != DZG_RUNNING && s->h_ctl->status != DZG_ITER_LIMIT) return 0;
+    if (s->h_ctl->status != DZG_RUNNING && s->h_ctl->status != DZG_ITER_LIMIT &&
+        s->h_ctl->status != DZG_NEAR_TIE)
+        return 0;
     if (counts[0] != s->h_ctl->ncompact)
         return fail(DZG_E_DEVICE, "refactor: structural basics != dense columns");
     dzg_launch_refactor(d, counts[0], counts[1], s->rfG, s->rfX, s->rf_ld, s->rf_piv, s->rf_spos,
@@ -578,15 +609,34 @@ extern "C" int dzg_solver_refactor(dzg_solver *s)
     return 0;
 }
 
+// iterations to enqueue before the next status poll: never past the run budget (an iteration
+// enqueued beyond it would be a no-op, but it would still cost its launches and exchanges)
+static int batch_size(const dzg_solver *s)
+{
+    const long long remaining = s->h_ctl->iter_stop - s->h_ctl->iter;
+    const int poll = s->opts.poll_interval;
+    return (int)(remaining < poll ? (remaining < 1 ? 1 : remaining) : poll);
+}
+
+// FAST health rule without a refactorisation workspace: the pivot element computed by FTRAN
+// and by BTRAN + pricing disagree beyond repair -> stop with DZG_SINGULAR rather than wander.
+static int health_stop(dzg_solver *s)
+{
+    if (s->h_ctl->max_pivot_err > 1e-4) {
+        int st = DZG_SINGULAR;
+        HIP_OK(hipMemcpy(&s->d.ctl->status, &st, sizeof(int), hipMemcpyHostToDevice));
+        s->h_ctl->status = st;
+    }
+    return 0;
+}
+
 static int run_fast(dzg_solver *s)
 {
-    const int poll = s->opts.poll_interval;
     for (;;) {
         if (s->opts.refactor_interval > 0 && s->since_refactor >= s->opts.refactor_interval)
             TRY(refactor_now(s));
         const long long before = s->h_ctl->iter;
-        long long remaining = s->h_ctl->iter_stop - before;
-        int batch = (int)(remaining < poll ? (remaining < 1 ? 1 : remaining) : poll);
+        const int batch = batch_size(s);
         if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
             TRY(shard_buffers(s));
             const size_t nb = sizeof(double) * (size_t)s->d.xstride;
@@ -607,14 +657,19 @@ static int run_fast(dzg_solver *s)
         HIP_OK(hipGetLastError());
         collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
-        // health: the pivot element computed by FTRAN and by BTRAN + pricing must agree
-        if (s->h_ctl->max_pivot_err > 1e-9 && s->rfG && s->since_refactor > 0) {
-            TRY(refactor_now(s)); // sheds the accumulated rounding, then carries on
-        } else if (s->h_ctl->max_pivot_err > 1e-4 && !s->rfG) {
-            int st = DZG_SINGULAR; // no refactor workspace: stop rather than wander
-            HIP_OK(hipMemcpy(&s->d.ctl->status, &st, sizeof(int), hipMemcpyHostToDevice));
-            s->h_ctl->status = st;
-            break;
+        // health: the pivot element computed by FTRAN and by BTRAN + pricing must agree.  A
+        // drift is shed by a refactorisation (workspace reserved on first need); only when that
+        // is impossible (out of memory) does the solve stop with DZG_SINGULAR.
+        if (s->h_ctl->max_pivot_err > s->drift_trigger && s->since_refactor > 0) {
+            // a basis whose fresh inverse drifts again at once is ill-conditioned, not stale:
+            // accept a larger disagreement instead of refactorising every batch
+            const bool fresh = s->refactors > 0 && s->since_refactor <= 2ll * s->opts.poll_interval;
+            if (fresh) s->drift_trigger *= 100.0;
+            if ((fresh && s->h_ctl->max_pivot_err > 1e-4) || refactor_now(s) != 0) {
+                s->h_ctl->max_pivot_err = 1.0;
+                TRY(health_stop(s));
+                break;
+            }
         }
     }
     return 0;
@@ -686,13 +741,20 @@ static int set_budget(dzg_solver *s, int64_t max_new_iters)
 {
     TRY(read_ctl(s));
     DzgCtl *h = s->h_ctl;
-    if (h->status != DZG_RUNNING && h->status != DZG_ITER_LIMIT) return h->status;
+    if (h->status != DZG_RUNNING && h->status != DZG_ITER_LIMIT && h->status != DZG_NEAR_TIE)
+        return h->status;
     long long stop = s->opts.max_iter;
     if (max_new_iters > 0 && h->iter + max_new_iters < stop) stop = h->iter + max_new_iters;
     if (h->status == DZG_ITER_LIMIT && h->iter >= s->opts.max_iter) return h->status;
+    if (h->status == DZG_NEAR_TIE) {
+        // resuming acknowledges the tie: the pivot in question is decided as FAST sees it
+        h->tie_skip_iter = h->iter;
+        HIP_OK(hipMemcpyAsync(&s->d.ctl->tie_skip_iter, &h->tie_skip_iter, sizeof(long long),
+                              hipMemcpyHostToDevice, s->st));
+    }
     h->status = DZG_RUNNING;
     h->iter_stop = stop;
-    // only these two words change; kernels are idle between runs
+    // only these words change; kernels are idle between runs
     HIP_OK(hipMemcpyAsync(&s->d.ctl->status, &h->status, sizeof(int), hipMemcpyHostToDevice, s->st));
     HIP_OK(hipMemcpyAsync(&s->d.ctl->iter_stop, &h->iter_stop, sizeof(long long), hipMemcpyHostToDevice, s->st));
     HIP_OK(hipStreamSynchronize(s->st));
@@ -821,7 +883,8 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
     auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const long long before = s->h_ctl->iter;
-        for (int b = 0; b < s->opts.poll_interval; ++b) {
+        const int batch = batch_size(s);
+        for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
             if (r.AllGather(s->xsend, s->xrecv1, n, kNcclFloat64, s->comm, s->st) != 0)
@@ -835,6 +898,10 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
         collect_profile(s, (int)(s->h_ctl->iter - before));
+        if (s->h_ctl->status != DZG_RUNNING) break;
+        // max_pivot_err comes from the replicated dx_p and the published dz_r: it is the same
+        // on every rank, so all ranks stop together
+        TRY(health_stop(s));
         if (s->h_ctl->status != DZG_RUNNING) break;
     }
     s->solve_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -862,7 +929,8 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         return 0;
     };
     for (;;) {
-        for (int b = 0; b < sv[0]->opts.poll_interval; ++b) {
+        const int batch = batch_size(sv[0]);
+        for (int b = 0; b < batch; ++b) {
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));
             TRY(exchange(false));
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase2(sv[r], sv[r]->xrecv1, sv[r]->xsend));
@@ -874,6 +942,8 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         for (int r = 1; r < world; ++r)
             if (sv[r]->h_ctl->status != sv[0]->h_ctl->status || sv[r]->h_ctl->iter != sv[0]->h_ctl->iter)
                 return fail(DZG_E_DEVICE, "lockstep: ranks diverged");
+        if (sv[0]->h_ctl->status != DZG_RUNNING) break;
+        for (int r = 0; r < world; ++r) TRY(health_stop(sv[r]));
         if (sv[0]->h_ctl->status != DZG_RUNNING) break;
     }
     return sv[0]->h_ctl->status;
@@ -951,49 +1021,61 @@ extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
     }
     res->price_bytes = s->h_ctl->price_bytes;
     res->solve_ms = s->solve_ms;
-    res->max_pivot_error = s->h_ctl->max_pivot_err;
+    res->max_pivot_error = s->max_err_life;
+    res->near_ties = s->h_ctl->near_ties;
+    res->first_near_tie = s->h_ctl->first_near_tie;
+    res->min_margin = s->h_ctl->min_margin;
+    res->dense_columns = s->numerics == DZG_NUMERICS_FAST ? s->h_ctl->ncompact : 0;
+    res->refactors = s->refactors;
+    if (res->margins && res->log_cap > 0 && s->numerics == DZG_NUMERICS_FAST) {
+        long long cnt = res->iterations < d.log_cap ? res->iterations : d.log_cap;
+        if (cnt > res->log_cap) cnt = res->log_cap;
+        if (cnt > 0)
+            HIP_OK(hipMemcpy(res->margins, d.log_margin, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
-extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res)
+static int solve_once(const dzg_lp *lp, const dzg_opts *o, dzg_result *res)
 {
-    if (!res) return fail(DZG_E_ARG, "res is NULL");
     dzg_solver *s = nullptr;
-    int rc = dzg_solver_create(lp, opts, &s);
+    int rc = dzg_solver_create(lp, o, &s);
     if (rc != 0) return rc;
     rc = dzg_solver_run(s, 0);
     if (rc < 0) {
         dzg_solver_destroy(s);
         return rc;
     }
-    int rc2 = dzg_solver_result(s, res);
+    const int rc2 = dzg_solver_result(s, res);
     dzg_solver_destroy(s);
-    if (rc2 != 0) return rc2;
-    // AUTO numerics chose FAST and FAST lost its footing (DZG_SINGULAR: the basis inverse no longer
-    // agrees with itself; DZG_PANIC: a non-finite step length) -- degenerate or badly scaled data.
-    // Up to a size STRICT finishes in reasonable time, answer with the reference's own arithmetic:
-    // what the caller of Simplex::solve would have got.
-    const bool automatic = !opts || opts->numerics == DZG_NUMERICS_AUTO;
-    if (automatic && res->numerics_used == DZG_NUMERICS_FAST && lp->m <= 2048 &&
-        (rc == DZG_SINGULAR || rc == DZG_PANIC)) {
-        dzg_opts strict;
-        if (opts)
-            strict = *opts;
-        else
-            dzg_opts_default(&strict);
+    return rc2 != 0 ? rc2 : rc;
+}
+
+extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res)
+{
+    if (!res) return fail(DZG_E_ARG, "res is NULL");
+    if (!lp) return fail(DZG_E_ARG, "lp is NULL");
+    dzg_opts o;
+    if (opts) o = *opts; else dzg_opts_default(&o);
+    const bool automatic = o.numerics == DZG_NUMERICS_AUTO;
+    const int strict_rows = o.auto_strict_rows > 0 ? o.auto_strict_rows : 192;
+    // AUTO above auto_strict_rows = FAST that must prove it followed the reference: up to
+    // DZG_AUTO_STRICT_RESTART_ROWS rows it stops at the first decision that is within rounding of
+    // a tie (and when it loses its footing: DZG_SINGULAR, DZG_PANIC -- degenerate or badly scaled
+    // data), and the LP is solved again from the first pivot in the reference's own arithmetic;
+    // the state vectors of a FAST run carry FAST's rounding, so no later point can be handed over
+    // bit-exactly.  Above that size STRICT is out of reach and FAST reports what it met.
+    const bool can_restart = automatic && lp->m > strict_rows && lp->m <= DZG_AUTO_STRICT_RESTART_ROWS;
+    if (can_restart && o.tie_tol >= 0.0) o.near_tie_action = DZG_NEAR_TIE_STOP;
+    int rc = solve_once(lp, &o, res);
+    if (rc < 0) return rc;
+    if (can_restart && res->numerics_used == DZG_NUMERICS_FAST &&
+        (rc == DZG_NEAR_TIE || rc == DZG_SINGULAR || rc == DZG_PANIC)) {
+        dzg_opts strict = o;
         strict.numerics = DZG_NUMERICS_STRICT;
         strict.refactor_interval = 0;
-        s = nullptr;
-        rc = dzg_solver_create(lp, &strict, &s);
-        if (rc != 0) return rc;
-        rc = dzg_solver_run(s, 0);
-        if (rc < 0) {
-            dzg_solver_destroy(s);
-            return rc;
-        }
-        rc2 = dzg_solver_result(s, res);
-        dzg_solver_destroy(s);
-        if (rc2 != 0) return rc2;
+        strict.near_tie_action = DZG_NEAR_TIE_COUNT;
+        rc = solve_once(lp, &strict, res);
     }
     return rc;
 }

@@ -36,19 +36,63 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define R_ DZG_RMAX
 
-__device__ __forceinline__ DzgCand reduce_partials(const double *__restrict__ pr,
-                                                   const int *__restrict__ pk, int count)
+__device__ __forceinline__ DzgCand2 reduce_partials(const double *__restrict__ pr,
+                                                    const int *__restrict__ pk,
+                                                    const double *__restrict__ ph, int count)
 {
-    DzgCand best;
-    best.r = 0.0;
-    best.k = -1;
+    DzgCand2 best = dzg_cand2_none();
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
-        DzgCand c;
+        DzgCand2 c;
         c.r = pr[i];
         c.k = pk[i];
-        best = dzg_better(best, c);
+        c.h = ph[i];
+        best = dzg_better2(best, c);
     }
-    return dzg_block_best(best);
+    return dzg_block_best2(best);
+}
+
+// ---------------------------------------------------------------------------------
+// Near-tie gate.  `margin` is the smallest relative margin of the decisions a kernel has just
+// taken (dzg_margin; absolute for the optimality test).  Inside the tolerance, stop mode ends
+// the run BEFORE the pivot with DZG_NEAR_TIE (every workgroup takes the same decision from the
+// same data, so all return together); count mode records it and carries on.  `first` marks the
+// first decision site of an iteration, which opens the per-pivot record.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool tie_gate(DzgCtl *ctl, const DzgCtl &c, bool lead, double margin,
+                                         bool first)
+{
+    const bool inside = !(margin > c.tau);
+    if (inside && c.tie_mode == 1 && c.iter != c.tie_skip_iter) {
+        if (lead) ctl->status = DZG_NEAR_TIE;
+        return true;
+    }
+    if (lead) {
+        ctl->margin = first ? margin : (margin < c.margin ? margin : c.margin);
+        ctl->tie_seen = (first ? 0 : c.tie_seen) | (inside ? 1 : 0);
+    }
+    return false;
+}
+
+// A terminal verdict (optimal / unbounded / infeasible) taken inside the tolerance executes no
+// pivot, so k_fast_pivot never books it: count it here.
+__device__ __forceinline__ void tie_book_terminal(DzgCtl *ctl, const DzgCtl &c, double margin)
+{
+    if (!(margin > c.tau)) {
+        ctl->near_ties = c.near_ties + 1;
+        if (c.first_near_tie < 0) ctl->first_near_tie = c.iter;
+    }
+    if (margin < c.min_margin) ctl->min_margin = margin;
+}
+
+// margin of a ratio test (find_second_pivot): argmax margin, and the winner itself must be
+// clearly positive -- a ratio that is positive only by rounding is excluded by the reference's
+// `ratio > 0.0` (src/simplex.rs:455); none found: trustworthy unless some ratio was not
+__device__ __forceinline__ double ratio_margin(DzgCand2 c, double tau)
+{
+    const double inf = __builtin_inf();
+    if (c.k < 0) return c.h == -inf ? inf : -1.0;
+    if (!(c.r > tau)) return 0.0;
+    return dzg_margin(c);
 }
 
 __device__ __forceinline__ double block_sum(double x)
@@ -64,22 +108,25 @@ __device__ __forceinline__ double block_sum(double x)
     return t;
 }
 
+// Merge of the ranks' proposals.  Slack positions are replicated, so several ranks may propose
+// the SAME position (with the same ratio): that is one candidate, not a tie.
 __device__ __forceinline__ int shard_merge(const double *__restrict__ xrecv, long long xstride,
-                                           int world, DzgCand &win)
+                                           int world, DzgCand2 &win)
 {
     int w = -1;
-    win.r = 0.0;
-    win.k = -1;
+    win = dzg_cand2_none();
     for (int r = 0; r < world; ++r) {
         const double *rec = xrecv + (long long)r * xstride;
-        DzgCand c;
+        DzgCand2 c;
         c.r = rec[0];
         c.k = (int)rec[1];
-        if (c.k < 0 || c.r != c.r) continue;
-        if (win.k < 0 || c.r > win.r || (c.r == win.r && c.k < win.k)) {
-            win = c;
-            w = r;
+        c.h = rec[6]; // the rank's own runner-up (or hazard mark)
+        if (c.k < 0 || c.r != c.r || c.k == win.k) {
+            if (c.h > win.h) win.h = c.h;
+            continue;
         }
+        win = dzg_better2(win, c);
+        if (win.k == c.k) w = r;
     }
     return w;
 }
@@ -101,58 +148,84 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
     const double *__restrict__ xrecv, long long xstride, int need_kind,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ fpx_r, const int *__restrict__ fpx_k,
-    const double *__restrict__ fpz_r, const int *__restrict__ fpz_k,
-    const double *__restrict__ rz_r, const int *__restrict__ rz_k, int nrz,
-    const double *__restrict__ W, long long ldw, const int *__restrict__ drow,
-    double *__restrict__ ag, double *__restrict__ beta, double eps, int world)
+    const double *__restrict__ fpx_h, const double *__restrict__ fpz_r,
+    const int *__restrict__ fpz_k, const double *__restrict__ fpz_h,
+    const double *__restrict__ rz_r, const int *__restrict__ rz_k,
+    const double *__restrict__ rz_h, int nrz, const double *__restrict__ W, long long ldw,
+    const int *__restrict__ drow, double *__restrict__ ag, double *__restrict__ beta, double eps,
+    int world)
 {
     DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
+    const double inf = __builtin_inf();
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     int epos;
     int code_known = 0, code_val = -1;
     if (MODE == 0 || MODE == 4) {
         // MODE 0: z-side first pivot from this GPU's partials.  MODE 4 (column sharding): from the
         // merge of every rank's proposal -- all ranks see the same records in the same order and
         // apply the same rule, so they take the same decision without a broadcast.
-        DzgCand cj;
+        DzgCand2 cj;
         int w = -1;
         if (MODE == 4)
             w = shard_merge(xrecv, xstride, world, cj);
         else
-            cj = reduce_partials(fpz_r, fpz_k, DZG_NB_UPD);
-        const DzgCand ci = reduce_partials(fpx_r, fpx_k, DZG_NB_UPD);
-        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-        int kind;
-        double mu;
+            cj = reduce_partials(fpz_r, fpz_k, fpz_h, DZG_NB_UPD);
+        const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, DZG_NB_UPD);
+        int kind = -1, verdict = DZG_RUNNING;
+        double mu = 0.0;
+        // margin of status(): the argmax of the side that is used, the primal-vs-dual comparison,
+        // the optimality test (absolute: eps is an absolute threshold), and no untrustworthy
+        // ratio on the side whose index is not used (its VALUE still enters the comparisons)
+        double margin = inf;
         if (cj.k >= 0 && ci.k >= 0) {
             const double primal = ci.r, dual = cj.r;
+            const double top = primal > dual ? primal : dual;
+            margin = fabs(top - eps);
             if (primal <= eps && dual <= eps) {
-                if (lead) ctl->status = DZG_OPTIMAL;
-                return;
-            }
-            if (primal < dual) {
-                kind = DZG_STEP_PRIMAL;
-                mu = dual;
+                verdict = DZG_OPTIMAL;
             } else {
-                kind = DZG_STEP_DUAL;
-                mu = primal;
+                const double a = fabs(primal), b = fabs(dual), den = a > b ? a : b;
+                const double cmp = den > 0.0 && den < inf ? fabs(primal - dual) / den
+                                                          : (primal == dual ? 0.0 : inf);
+                if (cmp < margin) margin = cmp;
+                if (primal < dual) {
+                    kind = DZG_STEP_PRIMAL;
+                    mu = dual;
+                } else {
+                    kind = DZG_STEP_DUAL;
+                    mu = primal;
+                }
             }
+            const double mj = kind == DZG_STEP_PRIMAL ? dzg_margin(cj) : (cj.h == inf ? -1.0 : inf);
+            const double mi = kind == DZG_STEP_DUAL ? dzg_margin(ci) : (ci.h == inf ? -1.0 : inf);
+            if (mj < margin) margin = mj;
+            if (mi < margin) margin = mi;
         } else if (cj.k >= 0) {
             kind = DZG_STEP_PRIMAL;
             mu = cj.r;
+            margin = dzg_margin(cj);
+            if (ci.h == inf) margin = -1.0;
         } else if (ci.k >= 0) {
             kind = DZG_STEP_DUAL;
             mu = ci.r;
+            margin = dzg_margin(ci);
+            if (cj.h == inf) margin = -1.0;
         } else {
-            if (lead) ctl->status = DZG_PANIC;
-            return;
+            verdict = DZG_PANIC;
+            if (ci.h == inf || cj.h == inf) margin = -1.0;
         }
-        if (c.iter >= c.iter_stop) {
+        if (verdict == DZG_RUNNING && c.iter >= c.iter_stop) {
             if (lead) ctl->status = DZG_ITER_LIMIT;
             return;
         }
-        if (m == 0) {
-            if (lead) ctl->status = DZG_PANIC;
+        if (verdict == DZG_RUNNING && m == 0) verdict = DZG_PANIC;
+        if (tie_gate(ctl, c, lead, margin, true)) return;
+        if (verdict != DZG_RUNNING) {
+            if (lead) {
+                ctl->status = verdict;
+                tie_book_terminal(ctl, c, margin);
+            }
             return;
         }
         if (lead) {
@@ -179,12 +252,16 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         // column sharding, second exchange.  Dual step: merge the ratio-test proposals (none =
         // Infeasible, src/simplex.rs:325), take the entering column and z, zbar, dz from the
         // winner's record.  Primal step: only z, zbar, dz of the entering position are needed.
-        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
         if (c.kind == DZG_STEP_DUAL) {
-            DzgCand cw;
+            DzgCand2 cw;
             const int w = shard_merge(xrecv, xstride, world, cw);
+            const double margin = ratio_margin(cw, c.tau);
+            if (tie_gate(ctl, c, lead, margin, false)) return;
             if (w < 0) {
-                if (lead) ctl->status = DZG_INFEASIBLE;
+                if (lead) {
+                    ctl->status = DZG_INFEASIBLE;
+                    tie_book_terminal(ctl, c, margin);
+                }
                 return;
             }
             const double *rec = xrecv + (long long)w * xstride;
@@ -219,13 +296,18 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         }
     } else {
         if (c.kind != DZG_STEP_DUAL) return;
-        const DzgCand c = reduce_partials(rz_r, rz_k, nrz);
-        if (c.k < 0) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status = DZG_INFEASIBLE; // :325
+        const DzgCand2 cw = reduce_partials(rz_r, rz_k, rz_h, nrz);
+        const double margin = ratio_margin(cw, c.tau);
+        if (tie_gate(ctl, c, lead, margin, false)) return;
+        if (cw.k < 0) {
+            if (lead) {
+                ctl->status = DZG_INFEASIBLE; // :325
+                tie_book_terminal(ctl, c, margin);
+            }
             return;
         }
-        epos = c.k;
-        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_pos = epos;
+        epos = cw.k;
+        if (lead) ctl->enter_pos = epos;
     }
     // ---- FTRAN preparation for the entering variable
     const int code = code_known ? code_val : var_col[nonbasis[epos]];
@@ -280,7 +362,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
                                           const int *__restrict__ var_col,
                                           const double *__restrict__ x,
                                           const double *__restrict__ xbar,
-                                          double *__restrict__ dx, DzgCand &best)
+                                          double *__restrict__ dx, DzgCand2 &best)
 {
     constexpr int RPW = 64 / LPR; // rows per wave and pass
     const int lane = threadIdx.x & 63;
@@ -288,7 +370,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int k2 = (k + 1) & ~1;
-    const double mu = ctl->mu;
+    const double mu = ctl->mu, tau = ctl->tau;
     for (int i0 = wave_global * RPW; i0 < m; i0 += nwaves * RPW) {
         const int i = i0 + grp;
         double acc = 0.0;
@@ -325,12 +407,14 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
             }
             dx[i] = acc;
             if (need_kind == DZG_STEP_PRIMAL) {
-                const double scaled = mu * xbar[i];
-                const double den = x[i] + scaled;
-                DzgCand cnd;
+                const double xi = x[i], scaled = mu * xbar[i];
+                const double den = xi + scaled;
+                DzgCand2 cnd;
                 cnd.r = dzg_div(acc, den);
                 cnd.k = i;
-                if (cnd.r > 0.0) best = dzg_better(best, cnd);
+                cnd.h = -__builtin_inf();
+                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
             }
         }
     }
@@ -343,16 +427,14 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
     const double *__restrict__ xrecv, long long xstride, const int *__restrict__ basis,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
-    double *__restrict__ rx_r, int *__restrict__ rx_k)
+    double *__restrict__ rx_r, int *__restrict__ rx_k, double *__restrict__ rx_h)
 {
     const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING || c.kind != need_kind) return;
     const int k = c.ncompact, neta = c.neta;
     const int code = c.enter_code;
     const double *acolp = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
-    DzgCand best;
-    best.r = 0.0;
-    best.k = -1;
+    DzgCand2 best = dzg_cand2_none();
     if (k > 512)
         gemv_rows<64>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
                       var_col, x, xbar, dx, best);
@@ -360,10 +442,11 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
         gemv_rows<16>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
                       var_col, x, xbar, dx, best);
     if (need_kind == DZG_STEP_PRIMAL) {
-        best = dzg_block_best(best);
+        best = dzg_block_best2(best);
         if (threadIdx.x == 0) {
             rx_r[blockIdx.x] = best.r;
             rx_k[blockIdx.x] = best.k;
+            rx_h[blockIdx.x] = best.h;
         }
     }
 }
@@ -377,20 +460,27 @@ __global__ __launch_bounds__(256) void k_fast_btran(
     DzgCtl *ctl, int m, const double *__restrict__ binv, long long ldb,
     const int *__restrict__ dslot, const int *__restrict__ basis, const int *__restrict__ var_col,
     const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
-    const double *__restrict__ rx_r, const int *__restrict__ rx_k, double *__restrict__ v)
+    const double *__restrict__ rx_r, const int *__restrict__ rx_k,
+    const double *__restrict__ rx_h, double *__restrict__ v)
 {
     __shared__ double s_up[R_];
     const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
     int p;
     if (c.kind == DZG_STEP_PRIMAL) {
-        const DzgCand c = reduce_partials(rx_r, rx_k, DZG_NB_GEMV);
-        if (c.k < 0) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) ctl->status = DZG_UNBOUNDED;
+        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+        const DzgCand2 cw = reduce_partials(rx_r, rx_k, rx_h, DZG_NB_GEMV);
+        const double margin = ratio_margin(cw, c.tau);
+        if (tie_gate(ctl, c, lead, margin, false)) return;
+        if (cw.k < 0) {
+            if (lead) {
+                ctl->status = DZG_UNBOUNDED;
+                tie_book_terminal(ctl, c, margin);
+            }
             return;
         }
-        p = c.k;
-        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->leave_pos = p;
+        p = cw.k;
+        if (lead) ctl->leave_pos = p;
     } else {
         p = c.leave_pos;
     }
@@ -419,7 +509,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     const int *__restrict__ var_col, double *binv, long long ldb, int *drow, int *dslot,
     double *U, long long ldu, double *W, long long ldw, int *plist, int *pslot, int col0, int col1,
     const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
-    double *log_mu, long long log_cap)
+    double *log_mu, double *log_margin, long long log_cap)
 {
     __shared__ int s_ok, s_k, s_ci, s_cj;
     // hop 1: the whole control block in one go (a couple of cache lines); every later decision
@@ -549,6 +639,17 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     ctl->del_last = del_last;
     ctl->neta = neta + 1;
     ctl->max_pivot_err = max_err;
+    // near-tie record of this pivot; the tolerance follows the health monitor
+    if (it < log_cap) log_margin[it] = c.margin;
+    if (c.margin < c.min_margin) ctl->min_margin = c.margin;
+    if (c.tie_seen) {
+        ctl->near_ties = c.near_ties + 1;
+        if (c.first_near_tie < 0) ctl->first_near_tie = it;
+    }
+    if (c.tie_tol >= 0.0) {
+        const double adaptive = 64.0 * max_err;
+        ctl->tau = adaptive > c.tie_tol ? adaptive : c.tie_tol;
+    }
     ctl->iter = it + 1;
 }
 
@@ -564,7 +665,8 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
                                                      const int *__restrict__ nonbasis,
                                                      const int *__restrict__ var_col, int col0,
                                                      int col1, int sharded, double *fpx_r,
-                                                     int *fpx_k, double *fpz_r, int *fpz_k,
+                                                     int *fpx_k, double *fpx_h, double *fpz_r,
+                                                     int *fpz_k, double *fpz_h,
                                                      const double *__restrict__ v,
                                                      double *__restrict__ U, long long ldu,
                                                      double *__restrict__ W, long long ldw,
@@ -590,9 +692,11 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
     double *wt = W + (long long)(teta < 0 ? 0 : teta) * ldw;
     const double t = c.t, s = c.s, tbar = c.tbar, sbar = c.sbar;
     const int stride = gridDim.x * blockDim.x;
-    DzgCand bx, bz;
-    bx.r = bz.r = 0.0;
-    bx.k = bz.k = -1;
+    // first-pivot candidates (src/simplex.rs:423-437) with their competition; a denominator
+    // that is zero up to rounding (ybar in [-tau, tau]) is a candidate the reference may or may
+    // not have -- with any ratio -- unless its numerator makes the ratio hopelessly negative
+    const double tau = c.tau, inf = __builtin_inf();
+    DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
         double xi = x[i], xb = xbar[i];
         if (!only_partials) {
@@ -606,11 +710,13 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
             wt[i] = (i == wzero) ? 0.0 : v[i];
         }
         if (xb > 0.0) {
-            DzgCand c;
+            DzgCand2 c;
             c.r = dzg_div(-xi, xb);
             c.k = i;
-            if (c.r == c.r) bx = dzg_better(bx, c);
+            c.h = -inf;
+            if (c.r == c.r) bx = dzg_better2(bx, c);
         }
+        if (fabs(xb) <= tau && !(xi > tau)) bx.h = inf;
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < q; k += stride) {
         double zk = z[k], zb = zbar[k];
@@ -628,19 +734,23 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
             mine = code < 0 || (code >= col0 && code < col1);
         }
         if (mine && zb > 0.0) {
-            DzgCand c;
+            DzgCand2 c;
             c.r = dzg_div(-zk, zb);
             c.k = k;
-            if (c.r == c.r) bz = dzg_better(bz, c);
+            c.h = -inf;
+            if (c.r == c.r) bz = dzg_better2(bz, c);
         }
+        if (mine && fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
     }
-    bx = dzg_block_best(bx);
-    bz = dzg_block_best(bz);
+    bx = dzg_block_best2(bx);
+    bz = dzg_block_best2(bz);
     if (threadIdx.x == 0) {
         fpx_r[blockIdx.x] = bx.r;
         fpx_k[blockIdx.x] = bx.k;
+        fpx_h[blockIdx.x] = bx.h;
         fpz_r[blockIdx.x] = bz.r;
         fpz_k[blockIdx.x] = bz.k;
+        fpz_h[blockIdx.x] = bz.h;
     }
 }
 
@@ -779,11 +889,11 @@ __global__ __launch_bounds__(256) void k_shard_propose(
     const DzgCtl *ctl, int m, const double *__restrict__ A, long long lda, int col0, int col1,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dz,
-    const double *__restrict__ pr, const int *__restrict__ pk, int np, double *__restrict__ rec,
-    int csc)
+    const double *__restrict__ pr, const int *__restrict__ pk, const double *__restrict__ ph,
+    int np, double *__restrict__ rec, int csc)
 {
     if (ctl->status != DZG_RUNNING) return;
-    double ratio = 0.0;
+    double ratio = 0.0, runner = -__builtin_inf();
     int pos = -1;
     bool want_column = true;
     if (MODE == 1 && ctl->kind == DZG_STEP_PRIMAL) {
@@ -794,9 +904,10 @@ __global__ __launch_bounds__(256) void k_shard_propose(
         }
         want_column = false; // FTRAN already happened
     } else {
-        const DzgCand c = reduce_partials(pr, pk, np);
+        const DzgCand2 c = reduce_partials(pr, pk, ph, np);
         pos = c.k;
         ratio = c.r;
+        runner = c.h;
     }
     const int code = pos >= 0 ? var_col[nonbasis[pos]] : -1;
     if (blockIdx.x == 0) {
@@ -807,7 +918,8 @@ __global__ __launch_bounds__(256) void k_shard_propose(
             rec[3] = pos >= 0 ? zbar[pos] : 0.0;
             rec[4] = (MODE == 1 && pos >= 0) ? dz[pos] : 0.0;
             rec[5] = (double)code;
-            rec[6] = rec[7] = 0.0;
+            rec[6] = runner; // competition inside this rank (DzgCand2::h)
+            rec[7] = 0.0;
         }
         return;
     }
@@ -856,8 +968,8 @@ void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const doubl
     //      2/3: prep only, selection already in the control block
     //      4: merge proposals + status + primal prep     5: merge second exchange + dual prep
 #define SEL_ARGS(need) d.ctl, d.m, d.A, d.lda, d.col0, xrecv, d.xstride, need, d.nonbasis, d.var_col,    \
-                       d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.rz_r, d.rz_k, nrz, d.W, d.ldw, d.drow, d.ag,  \
-                       d.beta, d.eps, d.world
+                       d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.rz_r, d.rz_k, d.rz_h, nrz,  \
+                       d.W, d.ldw, d.drow, d.ag, d.beta, d.eps, d.world
     const dim3 grid(R_ + 1), block(256);
     switch (mode) {
     case 0: hipLaunchKernelGGL((k_fast_select_prep<0>), grid, block, 0, st, SEL_ARGS(0)); break;
@@ -874,13 +986,14 @@ void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, h
 {
     hipLaunchKernelGGL(k_fast_gemv, dim3(DZG_NB_GEMV), dim3(256), 0, st, d.ctl, need_kind, d.m,
                        d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.col0, xrecv, d.xstride,
-                       d.basis, d.nonbasis, d.var_col, d.x, d.xbar, d.dx, d.rx_r, d.rx_k);
+                       d.basis, d.nonbasis, d.var_col, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h);
 }
 
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_btran, dim3((d.m + 255) / 256), dim3(256), 0, st, d.ctl, d.m, d.binv,
-                       d.ldb, d.dslot, d.basis, d.var_col, d.U, d.ldw, d.W, d.ldw, d.rx_r, d.rx_k, d.v);
+                       d.ldb, d.dslot, d.basis, d.var_col, d.U, d.ldw, d.W, d.ldw, d.rx_r, d.rx_k, d.rx_h,
+                       d.v);
 }
 
 void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st)
@@ -890,15 +1003,15 @@ void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st)
                        d.drow, d.dslot, d.U, d.ldw, d.W, d.ldw, d.plist, d.pslot, d.col0, d.col1,
                        d.csc ? d.cptr : nullptr, d.log_kind,
                        d.log_enter,
-                       d.log_leave, d.log_mu, d.log_cap);
+                       d.log_leave, d.log_mu, d.log_margin, d.log_cap);
 }
 
 void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
                        d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.nonbasis, d.var_col, d.col0, d.col1,
-                       d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpz_r, d.fpz_k, d.v, d.U, d.ldw, d.W,
-                       d.ldw, d.binv, d.ldb);
+                       d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.v, d.U,
+                       d.ldw, d.W, d.ldw, d.binv, d.ldb);
 }
 
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
@@ -917,11 +1030,11 @@ void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend,
     if (mode == 0)
         hipLaunchKernelGGL((k_shard_propose<0>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
                            d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.fpz_r,
-                           d.fpz_k, DZG_NB_UPD, xsend, d.csc);
+                           d.fpz_k, d.fpz_h, DZG_NB_UPD, xsend, d.csc);
     else
         hipLaunchKernelGGL((k_shard_propose<1>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
                            d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.rz_r, d.rz_k,
-                           nrz, xsend, d.csc);
+                           d.rz_h, nrz, xsend, d.csc);
     if (d.csc)
         hipLaunchKernelGGL(k_shard_scatter_col, dim3(1), dim3(256), 0, st, d.ctl, mode, d.cptr,
                            d.ridx, d.cval, d.col0, d.col1, xsend);

@@ -37,25 +37,30 @@ __device__ __forceinline__ int price_code(const int *__restrict__ nonbasis,
 }
 
 // ratio-test candidate of one position (src/simplex.rs:449-455): dz / (z + mu*zbar) if > 0
-__device__ __forceinline__ void price_candidate(DzgCand &best, double dzk, int pos, double mu,
-                                                const double *__restrict__ z,
+// (FAST numerics only: the candidate carries its competition for the near-tie arbitration, and
+// a denominator that is zero up to rounding marks the whole test untrustworthy -- the reference
+// may have +inf, which wins, NaN or a negative ratio there)
+__device__ __forceinline__ void price_candidate(DzgCand2 &best, double dzk, int pos, double mu,
+                                                double tau, const double *__restrict__ z,
                                                 const double *__restrict__ zbar)
 {
-    const double scaled = mu * zbar[pos];
-    const double den = z[pos] + scaled;
-    DzgCand c;
+    const double zk = z[pos], scaled = mu * zbar[pos];
+    const double den = zk + scaled;
+    DzgCand2 c;
     c.r = dzg_div(dzk, den);
     c.k = pos;
-    if (c.r > 0.0) best = dzg_better(best, c);
+    c.h = -__builtin_inf();
+    if (c.r > 0.0) best = dzg_better2(best, c);
+    if (dzg_noise_zero(den, zk, scaled, tau)) best.h = __builtin_inf();
 }
 
 // unit columns: every thread of the grid takes positions pos = tid, tid + nthreads, ...
-__device__ __forceinline__ void price_slack_positions(DzgCand &best, int q,
+__device__ __forceinline__ void price_slack_positions(DzgCand2 &best, int q,
                                                       const int *__restrict__ nonbasis,
                                                       const int *__restrict__ var_col,
                                                       const double *__restrict__ v,
                                                       double *__restrict__ dz, double mu,
-                                                      const double *__restrict__ z,
+                                                      double tau, const double *__restrict__ z,
                                                       const double *__restrict__ zbar)
 {
     const int nthreads = gridDim.x * blockDim.x;
@@ -65,18 +70,19 @@ __device__ __forceinline__ void price_slack_positions(DzgCand &best, int q,
             const double p = 1.0 * -v[-1 - code];
             const double d = 0.0 + p; // Iterator::sum identity + the single stored entry
             dz[pos] = d;
-            if (z) price_candidate(best, d, pos, mu, z, zbar);
+            if (z) price_candidate(best, d, pos, mu, tau, z, zbar);
         }
     }
 }
 
-__device__ __forceinline__ void price_publish(DzgCand best, double *__restrict__ rz_r,
-                                              int *__restrict__ rz_k)
+__device__ __forceinline__ void price_publish(DzgCand2 best, double *__restrict__ rz_r,
+                                              int *__restrict__ rz_k, double *__restrict__ rz_h)
 {
-    best = dzg_block_best(best);
+    best = dzg_block_best2(best);
     if (rz_r && threadIdx.x == 0) {
         rz_r[blockIdx.x] = best.r;
         rz_k[blockIdx.x] = best.k;
+        rz_h[blockIdx.x] = best.h;
     }
 }
 
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void k_price_seq2(
     const int *__restrict__ plist, const int *__restrict__ nonbasis,
     const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
-    int *__restrict__ rz_k, int col0 = 0)
+    int *__restrict__ rz_k, double *__restrict__ rz_h, int col0 = 0)
 {
     constexpr int TR = 128, PAD = 2; // column stride 130 doubles: lane c starts 4c banks on
     __shared__ __attribute__((aligned(16))) double tile[4][CW][TR + PAD];
@@ -99,11 +105,9 @@ __global__ __launch_bounds__(256) void k_price_seq2(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
     const int wg = blockIdx.x * 4 + wave;
-    const double mu = ctl ? ctl->mu : 0.0;
-    DzgCand best;
-    best.r = 0.0;
-    best.k = -1;
-    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, z, zbar);
+    const double mu = ctl ? ctl->mu : 0.0, tau = ctl ? ctl->tau : 0.0;
+    DzgCand2 best = dzg_cand2_none();
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, tau, z, zbar);
 
     const int count = plist ? (int)ctl->nb_struct : q;
     const int base = count / nw, rem = count % nw;
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(256) void k_price_seq2(
         }
         if (lane < nc && mycode >= 0) {
             dz[mypos] = acc;
-            if (z) price_candidate(best, acc, mypos, mu, z, zbar);
+            if (z) price_candidate(best, acc, mypos, mu, tau, z, zbar);
         }
     }
-    price_publish(best, rz_r, rz_k);
+    price_publish(best, rz_r, rz_k, rz_h);
 }
 
 // ---------------------------------------------------------------------------------
@@ -282,17 +286,15 @@ __global__ __launch_bounds__(256) void k_price_wave2(
     const int *__restrict__ plist, const int *__restrict__ nonbasis,
     const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
-    int *__restrict__ rz_k, int col0 = 0)
+    int *__restrict__ rz_k, double *__restrict__ rz_h, int col0 = 0)
 {
     if (ctl && ctl->status != DZG_RUNNING) return;
     const int lane = threadIdx.x & 63;
     const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nw = (gridDim.x * blockDim.x) >> 6;
-    const double mu = ctl ? ctl->mu : 0.0;
-    DzgCand best;
-    best.r = 0.0;
-    best.k = -1;
-    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, z, zbar);
+    const double mu = ctl ? ctl->mu : 0.0, tau = ctl ? ctl->tau : 0.0;
+    DzgCand2 best = dzg_cand2_none();
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, tau, z, zbar);
     const int count = plist ? (int)ctl->nb_struct : q;
     const int mpad = (m + 1) & ~1;
     for (int idx = wg; idx < count; idx += nw) {
@@ -331,10 +333,10 @@ __global__ __launch_bounds__(256) void k_price_wave2(
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, DZG_WAVE);
         if (lane == 0) {
             dz[pos] = -s;
-            if (z) price_candidate(best, -s, pos, mu, z, zbar);
+            if (z) price_candidate(best, -s, pos, mu, tau, z, zbar);
         }
     }
-    price_publish(best, rz_r, rz_k);
+    price_publish(best, rz_r, rz_k, rz_h);
 }
 
 // ---------------------------------------------------------------------------------
@@ -348,14 +350,13 @@ __global__ __launch_bounds__(256) void k_price_csc(
     const double *__restrict__ cval, int q, const int *__restrict__ plist,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ v, double *__restrict__ dz, const double *__restrict__ z,
-    const double *__restrict__ zbar, double *__restrict__ rz_r, int *__restrict__ rz_k, int col0)
+    const double *__restrict__ zbar, double *__restrict__ rz_r, int *__restrict__ rz_k,
+    double *__restrict__ rz_h, int col0)
 {
     if (ctl && ctl->status != DZG_RUNNING) return;
-    const double mu = ctl ? ctl->mu : 0.0;
-    DzgCand best;
-    best.r = 0.0;
-    best.k = -1;
-    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, z, zbar);
+    const double mu = ctl ? ctl->mu : 0.0, tau = ctl ? ctl->tau : 0.0;
+    DzgCand2 best = dzg_cand2_none();
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, tau, z, zbar);
     const int count = plist ? (int)ctl->nb_struct : q;
     // 8 lanes share one column: they fetch 8 consecutive stored entries at a time (coalesced
     // 64-B / 32-B segments) and form the 8 products in parallel; the running sum then takes the
@@ -395,10 +396,10 @@ __global__ __launch_bounds__(256) void k_price_csc(
         }
         if (code >= 0 && sub == 0) {
             dz[pos] = acc;
-            if (z) price_candidate(best, acc, pos, mu, z, zbar);
+            if (z) price_candidate(best, acc, pos, mu, tau, z, zbar);
         }
     }
-    price_publish(best, rz_r, rz_k);
+    price_publish(best, rz_r, rz_k, rz_h);
 }
 
 #define DZG_PRICE_CSC_BLOCKS 2048

@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256) void k_ref_gather_slack(int k, const double *_
 __global__ void k_ref_done(DzgCtl *ctl, const int *__restrict__ singular)
 {
     ctl->neta = 0;
+    // the health monitor restarts with the fresh inverse (the host keeps the lifetime maximum
+    // for reporting): a drift that was shed must not trigger a refactorisation per batch
+    ctl->max_pivot_err = 0.0;
     if (*singular) ctl->status = DZG_SINGULAR;
 }
 

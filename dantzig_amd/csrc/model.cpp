@@ -276,6 +276,8 @@ extern "C" int dzg_model_solve(const dzg_model *md, const dzg_opts *opts, dzg_mo
     res->numerics_used = r.numerics_used;
     res->iterations = r.iterations;
     res->objective = r.objective;
+    res->near_ties = r.near_ties;
+    res->first_near_tie = r.first_near_tie;
     if (rc < 0) return rc;
     if (res->values) { // Simplex::solution, src/simplex.rs:354-371
         std::vector<int64_t> pos_of((size_t)(b.n ? b.n : 1), -1);

@@ -12,3 +12,8 @@ class UnboundedError(SolveError):
 
 class InfeasibleError(SolveError):
     """No point satisfies all constraints (src/simplex.rs:325)."""
+
+
+class NearTieWarning(UserWarning):
+    """FAST numerics met a pivot choice within rounding of a tie on a model too large for the
+    bit-exact re-solve (not in the reference: it has one arithmetic only)."""

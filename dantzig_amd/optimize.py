@@ -16,7 +16,7 @@ _SENSES = ("minimize", "maximize")
 class Solution:
     def __init__(self, *, solution: rs.PySolution, sense: str) -> None:
         if sense not in _SENSES:
-            raise ValueError("'sense' must be one of ['minimize', 'maximize']")
+            raise ValueError(f"sense is {sense!r}; a Solution is built for {_SENSES[0]!r} or {_SENSES[1]!r}")
         self._solution = solution
         self._sense = sense
 
@@ -43,12 +43,11 @@ class Optimize(abc.ABC):
 
     def subject_to(self, constraints):
         """Add one constraint or a list of constraints; returns self for chaining."""
-        if isinstance(constraints, list):
-            self.constraints.extend(constraints)
-        elif isinstance(constraints, Constraint):
-            self.constraints.append(constraints)
-        else:
-            raise TypeError(f"unexpected constraint type {type(constraints)}")
+        batch = [constraints] if isinstance(constraints, Constraint) else constraints
+        if not isinstance(batch, list):  # like the reference, list items are not inspected here
+            raise TypeError("subject_to takes a Constraint or a list of Constraints, got "
+                            f"{type(constraints).__name__}")
+        self.constraints += batch
         return self
 
     st = subject_to

@@ -17,11 +17,12 @@ from __future__ import annotations
 import ctypes as C
 import itertools
 import threading
+import warnings
 
 import numpy as np
 
 from . import _ffi
-from .exceptions import InfeasibleError, UnboundedError
+from .exceptions import InfeasibleError, NearTieWarning, UnboundedError
 
 _counter = itertools.count()          # static COUNTER: AtomicUsize, src/pyobjs.rs:8
 _counter_lock = threading.Lock()
@@ -218,6 +219,13 @@ def solve(objective: PyAffExpr, constraints) -> PySolution:
         # PANIC / ITER_LIMIT / SINGULAR: the reference would panic (PanicException) or recurse
         raise RuntimeError(f"simplex terminated with status {_ffi.status_str(rc)!r} after "
                            f"{res.iterations} iterations")
+    if res.near_ties > 0 and res.numerics_used != _ffi.STRICT:
+        warnings.warn(
+            f"{res.near_ties} of {res.iterations} pivots (the first: pivot {res.first_near_tie}) were "
+            "decided within rounding distance of a tie and the model is too large to be re-solved "
+            "in the reference's own arithmetic: the optimum is valid, but the vertex may differ "
+            "from the one the reference implementation reports when the optimum is not unique",
+            NearTieWarning, stacklevel=3)
     return PySolution(float(res.objective), {v.id: float(values[i]) for i, v in enumerate(order)},
                       int(res.iterations), "strict" if res.numerics_used == _ffi.STRICT else "fast",
                       (int(res.m), int(res.n)))

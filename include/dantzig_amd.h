@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DZG_ABI_VERSION 1
+#define DZG_ABI_VERSION 2
 
 /* Outcome codes.  0..2 mirror the reference: Ok / Error::Unbounded / Error::Infeasible
  * (src/error.rs:3-7, src/simplex.rs:313,325).  The rest do not exist in the
@@ -44,6 +44,12 @@ typedef enum {
     DZG_PANIC = 5,        /* a reference panic path: safe_divide assert (src/simplex.rs:466),
                              "unexpected code path" (:304), zero-row LP (n-1 underflow) */
     DZG_RUNNING = 6,      /* internal: not terminated yet                              */
+    DZG_NEAR_TIE = 7,     /* fast numerics, opts.near_tie_action = STOP: stopped BEFORE a pivot
+                             whose choice (status(), find_first_pivot, find_second_pivot,
+                             src/simplex.rs:274-306,423-461) is within rounding of a tie, so the
+                             reference's arithmetic may choose differently.  The state is that
+                             of the last executed pivot; dzg_solver_run resumes (that decision is
+                             then taken as FAST sees it and counted in near_ties)         */
     DZG_E_DEVICE = -1,    /* HIP error, or no usable GPU (the product has no CPU path) */
     DZG_E_ARG = -2,       /* malformed input                                           */
     DZG_E_NOMEM = -3
@@ -108,7 +114,8 @@ typedef struct {
     double epsilon;           /* optimality tolerance, default 1e-12 (src/simplex.rs:9) */
     int64_t log_capacity;     /* pivots kept in the device log, default min(max_iter, 2^22) */
     int32_t poll_interval;    /* FAST: iterations enqueued between host status polls, default 32 */
-    int32_t profile;          /* 1: time every kernel class with HIP events (slower)    */
+    int32_t profile;          /* bit mask, bit (1 << DZG_K_*) set: time that kernel class with
+                                 HIP events (slower); 0 = no timing, -1 = every class    */
     /* Column sharding (one process per GPU).  This rank prices the structural columns
      * [col_begin, col_end); 0,0 = all.  See dzg_shard_* below. */
     int64_t col_begin, col_end;
@@ -123,8 +130,21 @@ typedef struct {
                                  [col_begin, col_end) (column col_begin first), so a rank never
                                  materialises the other ranks' part of the matrix; 0 = lp->a is
                                  the whole m x n_struct matrix and the block is taken from it   */
-    int32_t reserved0;
+    int32_t near_tie_action;  /* FAST: dzg_near_tie_action, default COUNT                       */
+    double tie_tol;           /* FAST: a decision of the pivot rule is a "near tie" when winner and
+                                 runner-up differ by less than max(tie_tol, 64 * max_pivot_error)
+                                 relative, or rest on a denominator that is zero up to that
+                                 tolerance.  Default 1e-11; < 0 switches the detector off       */
 } dzg_opts;
+
+/* What FAST numerics does at a near tie (the pivot rule is a first-wins strict argmax,
+ * src/simplex.rs:432-435,456-459: inside rounding distance of a tie, FAST's rounding and the
+ * reference's can disagree, and only the reference's own arithmetic -- STRICT, from the first
+ * pivot -- can say which way the reference goes). */
+typedef enum {
+    DZG_NEAR_TIE_COUNT = 0,   /* carry on; count such pivots in dzg_result.near_ties             */
+    DZG_NEAR_TIE_STOP = 1     /* stop with DZG_NEAR_TIE before the pivot is executed             */
+} dzg_near_tie_action;
 
 typedef struct {
     int32_t kind;       /* dzg_step_kind           */
@@ -159,6 +179,15 @@ typedef struct {
     double solve_ms;         /* wall time inside dzg_solver_run, summed                  */
     double max_pivot_error;  /* FAST health monitor: max relative |dx_p + dz_r| over all pivots
                                 (the pivot element computed by FTRAN vs by BTRAN + pricing)   */
+    /* FAST near-tie arbitration: the pivot log is the reference's, decision by decision, up to
+     * (not including) pivot `first_near_tie`; near_ties == 0 means the whole log is.            */
+    int64_t near_ties;       /* executed pivots with a decision inside the tie tolerance        */
+    int64_t first_near_tie;  /* iteration index of the first one, -1 if none                    */
+    double min_margin;       /* smallest relative margin (winner - runner-up) of any decision   */
+    double *margins;         /* optional, like `log`: per-pivot smallest margin, log_cap entries */
+    /* FAST basis representation */
+    int64_t dense_columns;   /* k: structural variables in the basis = dense columns of the inverse */
+    int64_t refactors;       /* refactorisations performed so far                               */
 } dzg_result;
 
 typedef struct dzg_solver dzg_solver;
@@ -184,9 +213,14 @@ void dzg_solver_destroy(dzg_solver *s);
 /* FAST: rebuild the basis inverse from scratch now (needs opts.refactor_interval != 0 at
  * creation, which reserves the workspace). */
 int dzg_solver_refactor(dzg_solver *s);
-/* create + run + result + destroy.  With opts == NULL or numerics AUTO, a FAST run (more than
- * auto_strict_rows rows) that ends in DZG_SINGULAR / DZG_PANIC is repeated with STRICT numerics --
- * the reference's arithmetic -- for LPs of up to 2048 rows, and that result is returned. */
+/* create + run + result + destroy.  With opts == NULL or numerics AUTO and more than
+ * auto_strict_rows rows, FAST runs with near_tie_action = STOP.  Up to DZG_AUTO_STRICT_RESTART_ROWS
+ * rows, a run that meets a near tie (or ends in DZG_SINGULAR / DZG_PANIC) is abandoned and the LP
+ * is solved again from the first pivot with STRICT numerics -- the reference's arithmetic, the only
+ * arbiter of a tie -- and that result is returned.  Above that size STRICT is out of reach
+ * (seconds per pivot): FAST carries on and the result reports near_ties / first_near_tie, so the
+ * caller knows from which pivot on the path is no longer certified to be the reference's. */
+#define DZG_AUTO_STRICT_RESTART_ROWS 2048
 int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res);
 
 /* ---- Level 2: replaces dantzig.rust.solve (src/lib.rs:16-27) ---------------------- */
@@ -217,6 +251,9 @@ typedef struct {
     double objective;     /* PySolution.objective_value (core sense: maximised)         */
     double *values;       /* nvars: x+ - x- per user variable (src/simplex.rs:354-371)  */
     int64_t m, n;         /* size of the standard form that was solved                  */
+    int64_t near_ties;    /* FAST on an LP too large for a STRICT re-solve: pivots decided inside
+                             the tie tolerance (0: the path is the reference's), see dzg_result */
+    int64_t first_near_tie;
 } dzg_model_result;
 
 int dzg_model_solve(const dzg_model *model, const dzg_opts *opts, dzg_model_result *res);

@@ -302,10 +302,11 @@ def _outcome(seed, numerics):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1, 4, 5, 11])
 def test_auto_numerics_falls_back_to_strict_when_fast_gives_up(seed):
-    """Above auto_strict_rows AUTO runs FAST; when FAST stops with DZG_SINGULAR / DZG_PANIC,
-    Level 2 answers with the reference's own arithmetic (STRICT) instead of an error."""
+    """Above auto_strict_rows AUTO runs FAST; when FAST meets a near tie or loses its footing
+    (DZG_SINGULAR / DZG_PANIC), Level 2 answers with the reference's own arithmetic (STRICT)
+    instead of an error.  On these 0/1 models explicit FAST does lose it."""
     from dantzig_amd import _ffi
 
     fast = _outcome(seed, _ffi.FAST)
-    assert fast[0] == "RuntimeError" and "singular" in fast[1]
+    assert fast[0] == "RuntimeError" and ("singular" in fast[1] or "panic" in fast[1])
     assert _outcome(seed, _ffi.AUTO) == _outcome(seed, _ffi.STRICT)

@@ -81,15 +81,15 @@ int main(int argc, char **argv)
         fflush(stdout);
     };
 #define ARGS nullptr, A, lda, m, ns, nullptr, cols, nullptr, v
-    hipLaunchKernelGGL((k_price_seq2<16>), dim3(256), dim3(256), 0, 0, ARGS, ref, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_price_seq2<16>), dim3(256), dim3(256), 0, 0, ARGS, ref, nullptr, nullptr, nullptr, nullptr, nullptr);
     CK(hipDeviceSynchronize());
     time_it("stream U=4 (2048 blk)", [&] { hipLaunchKernelGGL((k_stream<4>), dim3(2048), dim3(256), 0, 0, A, na / 2, dz); }, false);
-#define SEQ2(CW, BLK) time_it("seq2<" #CW "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
+#define SEQ2(CW, BLK) time_it("seq2<" #CW "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr, nullptr); }, true)
     SEQ2(16, 256);
-#define SEQ2D(CW, DEP, DBG, NT, BLK) time_it("seq2<" #CW "," #DEP "," #DBG "," #NT "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW, DEP, DBG, NT>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
+#define SEQ2D(CW, DEP, DBG, NT, BLK) time_it("seq2<" #CW "," #DEP "," #DBG "," #NT "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_seq2<CW, DEP, DBG, NT>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr, nullptr); }, true)
     SEQ2D(16, 3, 0, true, 256); SEQ2D(16, 3, 1, true, 256); SEQ2D(8, 3, 0, true, 512); SEQ2D(8, 4, 0, true, 512); SEQ2D(16, 2, 0, true, 256); SEQ2D(16, 4, 0, true, 256);
     {
-        hipLaunchKernelGGL((k_price_seq2<16, 3, 4, true>), dim3(256), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((k_price_seq2<16, 3, 4, true>), dim3(256), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr, nullptr);
         CK(hipDeviceSynchronize());
         std::vector<double> st(3 * 1024);
         CK(hipMemcpy(st.data(), dz + ns, st.size() * 8, hipMemcpyDeviceToHost));
@@ -98,7 +98,7 @@ int main(int argc, char **argv)
         int nt = (m + 127) / 128;
         printf("stamps (avg cycles per tile per wave): park+wait %.0f  fetch %.0f  walk %.0f\n", a / 1024 / nt, b / 1024 / nt, c / 1024 / nt);
     }
-#define WAVE2(U, BLK) time_it("wave2<" #U "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_wave2<U>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr); }, true)
+#define WAVE2(U, BLK) time_it("wave2<" #U "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_wave2<U>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr, nullptr); }, true)
     WAVE2(4, 2048); WAVE2(4, 4096);
     return 0;
 }
