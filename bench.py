@@ -8,7 +8,12 @@ fp64 LP (generator G1, seed 1003).  One "step" = one executed pivot
 between barriers, continuing the same solve trajectory.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--rows M --cols NS --seed S]
-                  [--price seq|wave] [--no-cpu-baseline] [--no-pmc-traffic] [--no-secondary]
+                  [--price tree|seq|wave] [--no-cpu-baseline] [--no-pmc-traffic] [--no-secondary]
+                  [--no-late] [--late-pivots N]
+
+`value` is the rate of the K pivots that follow the warm-up (an almost empty basis inverse); the
+"late" block times K more pivots of the same solve after --late-pivots pivots, with the basis
+inverse grown (config.k_at_* / late.k_at_* = its dense columns) and a per-kernel-class split.
 
 The default invocation also measures config 5 (32768 x 65536, the LP the multi-GPU target is quoted
 on) and reports it under "secondary"; `value` is always the 8192 x 16384 LP.
@@ -59,6 +64,33 @@ def cpu_baseline(sample_rows: int, sample_cols: int, seed: int, pivots: int, row
     }
 
 
+def _run_in_own_group(cmd, cwd, env, timeout):
+    """Runs a child in its own process group and, on a timeout, ends the WHOLE group: rocprofv3
+    starts the profiled program as a grandchild, which would otherwise keep the GPU busy while
+    this process goes on to the timed measurement."""
+    import signal
+    import subprocess
+
+    proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL,
+                            stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        rc = proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise
+    if rc != 0:
+        raise RuntimeError(f"{cmd[0]} exited with {rc}")
+
+
 def pmc_traffic(args) -> dict | None:
     """HBM bytes per launch of the pricing kernel from the rocprofv3 PMC counters, collected in
     two separate child runs (FETCH_SIZE and WRITE_SIZE do not fit one pass) BEFORE this process
@@ -67,7 +99,6 @@ def pmc_traffic(args) -> dict | None:
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
 
     exe = shutil.which("rocprofv3")
@@ -77,21 +108,25 @@ def pmc_traffic(args) -> dict | None:
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = tempfile.mkdtemp(prefix="dzg_pmc_", dir="/tmp")
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
-                   sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "20",
-                   "--rows", str(args.rows), "--cols", str(args.cols), "--seed", str(args.seed),
-                   "--price", args.price, "--no-cpu-baseline", "--no-pmc-traffic", "--no-secondary"]
-            env = dict(os.environ, TMPDIR="/tmp")
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=240, check=True)
-            total, n = 0.0, 0
-            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if row["Counter_Name"] == counter and "k_price_" in row["Kernel_Name"]:
-                            total += float(row["Counter_Value"])
-                            n += 1
-            shutil.rmtree(out, ignore_errors=True)
+            try:
+                cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                       sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "20",
+                       "--rows", str(args.rows), "--cols", str(args.cols), "--seed", str(args.seed),
+                       "--price", args.price, "--no-cpu-baseline", "--no-pmc-traffic",
+                       "--no-secondary", "--no-late"]
+                if args.sparse_per_col > 0:
+                    cmd += ["--sparse-per-col", str(args.sparse_per_col)]
+                _run_in_own_group(cmd, "/tmp", dict(os.environ, TMPDIR="/tmp"), 240)
+                total, n = 0.0, 0
+                for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"),
+                                      recursive=True):
+                    with open(path) as f:
+                        for row in csv.DictReader(f):
+                            if row["Counter_Name"] == counter and "k_price_" in row["Kernel_Name"]:
+                                total += float(row["Counter_Value"])
+                                n += 1
+            finally:
+                shutil.rmtree(out, ignore_errors=True)
             if n == 0:
                 return None
             per_launch[counter] = total / n * 1024.0
@@ -122,8 +157,65 @@ def secondary_wanted(args) -> bool:
             and args.cols == 16384 and args.sparse_per_col == 0 and args.numerics == "fast")
 
 
-def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, warmup) -> dict:
-    """One workload on one GPU: generate, upload (untimed), `warmup` pivots, then `steps` timed."""
+PRICE_KERNELS = {"auto": "k_price_tree", "tree": "k_price_tree", "seq": "k_price_seq2",
+                 "wave": "k_price_wave2"}
+
+
+def _pricing(r0, r1, kernel: str) -> dict:
+    """Roofline block of the pricing kernel between two result snapshots."""
+    ms = r1.kernel_ms["price"] - r0.kernel_ms["price"]
+    launches = r1.kernel_launches["price"] - r0.kernel_launches["price"]
+    nbytes = r1.price_bytes - r0.price_bytes
+    achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else float("nan")
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
+            "algorithmic_bytes_per_launch": nbytes / max(launches, 1)}
+
+
+def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
+    """The same solve deep into its trajectory: `late_pivots` pivots are skipped untimed (the
+    basis inverse has grown to k dense columns by then, so FTRAN, the eta flush and the update
+    cost what they cost for most of a whole solve), then `steps` pivots are timed like the
+    primary region, then 256 more with every kernel class stamped for the per-class split."""
+    from dantzig_amd import _ffi
+
+    skip = late_pivots - r1.iterations
+    status = solver.run(skip) if skip > 0 else "iter_limit"
+    if status != "iter_limit":
+        return {"skipped": f"solve ended ({status}) before pivot {late_pivots}"}
+    ra = solver.result(log=False)
+    t0 = time.perf_counter()
+    status = solver.run(steps)
+    elapsed = time.perf_counter() - t0
+    rb = solver.result(log=False)
+    done = rb.iterations - ra.iterations
+    out = {"untimed_pivots_before": ra.iterations, "steps": done,
+           "value": done / elapsed if elapsed > 0 else float("nan"), "unit": "iterations/s",
+           "ms_per_step": 1e3 * elapsed / max(done, 1),
+           "k_at_start": ra.dense_columns, "k_at_end": rb.dense_columns,
+           "max_pivot_error": rb.max_pivot_error, "near_ties": rb.near_ties,
+           "refactors": rb.refactors, "roofline": _pricing(ra, rb, kernel)}
+    if status == "iter_limit":
+        solver.set_profile((1 << _ffi.K_COUNT) - 1)
+        solver.run(256)
+        rc = solver.result(log=False)
+        n = max(rc.iterations - rb.iterations, 1)
+        names = {"status": "status + primal FTRAN prep", "ftran": "FTRAN GEMV (primal)",
+                 "btran": "BTRAN row", "price": "pricing", "ratio": "dual ratio + prep + FTRAN GEMV",
+                 "update": "pivot + update", "basis_update": "eta flush (amortised)"}
+        out["kernel_us_per_pivot"] = {
+            label: round(1e3 * (rc.kernel_ms[k] - rb.kernel_ms[k]) / n, 2)
+            for k, label in names.items()}
+        out["kernel_us_note"] = (f"HIP events around each kernel class over {n} further pivots "
+                                 "(event overhead included; not part of any reported rate)")
+    return out
+
+
+def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, warmup,
+            late_pivots: int = 0) -> dict:
+    """One workload on one GPU: generate, upload (untimed), `warmup` pivots, then `steps` timed;
+    with late_pivots > 0 a second timed region deep in the same solve (see _late_regime)."""
     from dantzig_amd import _ffi, core
 
     t_gen = time.perf_counter()
@@ -134,12 +226,16 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
         a, b, c = core.gen_dense_lp(seed=seed, m=rows, n_struct=cols)
         lp = core.CoreLP.from_inequality_form(a, b, c)
     t_gen = time.perf_counter() - t_gen
-    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[price_name]
+    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
+             "tree": core.PRICE_TREE}[price_name]
     numerics = core.FAST if numerics_name == "fast" else core.STRICT
+    kernel = "k_price_csc" if sparse_per_col > 0 else (
+        "k_price_seq2" if numerics_name == "strict" else PRICE_KERNELS[price_name])
     t_up = time.perf_counter()
     solver = core.Solver(lp, numerics=numerics, price_kernel=price,
                          profile=1 << _ffi.K_PRICE, poll_interval=50)
     t_up = time.perf_counter() - t_up
+    late = None
     try:
         status = solver.run(warmup) if warmup > 0 else "iter_limit"
         r0 = solver.result(log=False)
@@ -148,16 +244,14 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
             status = solver.run(steps)
         t1 = time.perf_counter()
         r1 = solver.result(log=False)
+        if late_pivots > 0 and status == "iter_limit" and numerics_name == "fast":
+            late = _late_regime(solver, r1, steps, late_pivots, kernel)
     finally:
         solver.close()
 
     steps_done = r1.iterations - r0.iterations
     elapsed = t1 - t0
-    price_ms = r1.kernel_ms["price"] - r0.kernel_ms["price"]
-    price_launches = r1.kernel_launches["price"] - r0.kernel_launches["price"]
-    price_bytes = r1.price_bytes - r0.price_bytes
-    achieved = (price_bytes / 1e9) / (price_ms / 1e3) if price_ms > 0 else float("nan")
-    return {
+    out = {
         "metric": "simplex_iterations_per_sec",
         "value": steps_done / elapsed if elapsed > 0 else float("nan"),
         "unit": "iterations/s",
@@ -179,25 +273,19 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
             "price_kernel": price_name,
             "status_after_timed_region": status,
             "requested_steps": steps,
+            "k_at_start": r0.dense_columns,
+            "k_at_end": r1.dense_columns,
             "lp_generation_s": round(t_gen, 3),
             "upload_s": round(t_up, 3),
             "max_pivot_error": r1.max_pivot_error,
+            "near_ties": r1.near_ties,
+            "first_near_tie": r1.first_near_tie,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": ("k_price_csc" if sparse_per_col > 0 else "k_price_seq2"
-                       if (price_name == "seq" or (price_name == "auto" and cols >= 12288))
-                       else "k_price_wave2"),
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "avg_launch_us": 1e3 * price_ms / max(price_launches, 1),
-            "launches": price_launches,
-            "algorithmic_bytes_per_launch": price_bytes / max(price_launches, 1),
-        },
+        "roofline": _pricing(r0, r1, kernel),
     }
+    if late is not None:
+        out["late"] = late
+    return out
 
 
 def main() -> int:
@@ -208,10 +296,14 @@ def main() -> int:
     ap.add_argument("--rows", type=int, default=8192)
     ap.add_argument("--cols", type=int, default=16384)
     ap.add_argument("--seed", type=int, default=1003)
-    ap.add_argument("--price", choices=["auto", "seq", "wave"], default="auto")
+    ap.add_argument("--price", choices=["auto", "tree", "seq", "wave"], default="auto")
     ap.add_argument("--numerics", choices=["fast", "strict"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc-traffic", action="store_true")
+    ap.add_argument("--no-late", action="store_true",
+                    help="skip the second timed region deep in the solve (the \"late\" block)")
+    ap.add_argument("--late-pivots", type=int, default=20000,
+                    help="pivots skipped untimed before the late region (default 20000, ~4 s)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the 32768x65536 measurement that rides along with the default run")
     ap.add_argument("--sparse-per-col", type=int, default=0,
@@ -254,8 +346,9 @@ def main() -> int:
     # one HIP runtime per process: the library's.  dzg_solver_run returns after synchronising
     # its stream, which brackets the timed region the way torch.cuda.synchronize() would.
     _ffi.require_gpu()
+    late_pivots = 0 if (args.no_late or under_profiler()) else args.late_pivots
     out = measure(args.rows, args.cols, args.seed, args.sparse_per_col, args.price, args.numerics,
-                  args.steps, args.warmup)
+                  args.steps, args.warmup, late_pivots)
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
     out["roofline"]["traffic_detail"] = traffic
     if under_profiler():

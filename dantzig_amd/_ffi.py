@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libdantzig_amd.so")
 OPTIMAL, UNBOUNDED, INFEASIBLE, ITER_LIMIT, SINGULAR, PANIC, RUNNING, NEAR_TIE = range(8)
 E_DEVICE, E_ARG, E_NOMEM = -1, -2, -3
 STRICT, FAST, AUTO = 0, 1, 2
-PRICE_AUTO, PRICE_SEQ, PRICE_WAVE = 0, 1, 2
+PRICE_AUTO, PRICE_SEQ, PRICE_WAVE, PRICE_TREE = 0, 1, 2, 3
 STEP_PRIMAL, STEP_DUAL = 0, 1
 NEAR_TIE_COUNT, NEAR_TIE_STOP = 0, 1
 K_STATUS, K_FTRAN, K_RATIO, K_BTRAN, K_PRICE, K_UPDATE, K_BASIS_UPDATE, K_LU, K_COUNT = range(9)
@@ -33,7 +33,7 @@ EXPORTS = [
     "dzg_shard_record_doubles", "dzg_shard_phase1", "dzg_shard_phase2", "dzg_shard_phase3",
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
-    "dzg_gen_dense_lp_block",
+    "dzg_gen_dense_lp_block", "dzg_solver_set_profile",
 ]
 
 
@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
         _lib.dzg_solver_stream.restype = C.c_void_p
         _lib.dzg_solver_stream.argtypes = [C.c_void_p]
         _lib.dzg_solver_refactor.argtypes = [C.c_void_p]
+        _lib.dzg_solver_set_profile.argtypes = [C.c_void_p, C.c_int32]
     return _lib
 
 

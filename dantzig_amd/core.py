@@ -12,7 +12,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _ffi
-from ._ffi import (AUTO, FAST, STRICT, PRICE_AUTO, PRICE_SEQ, PRICE_WAVE, STEP_DUAL,  # noqa: F401
+from ._ffi import (AUTO, FAST, STRICT, PRICE_AUTO, PRICE_SEQ, PRICE_WAVE, PRICE_TREE,  # noqa: F401
+                   STEP_DUAL,
                    STEP_PRIMAL, NEAR_TIE_COUNT, NEAR_TIE_STOP, DantzigAmdError, f64, i64, ptr)
 
 STATUS_NAMES = {0: "optimal", 1: "unbounded", 2: "infeasible", 3: "iter_limit", 4: "singular",
@@ -196,6 +197,10 @@ class Solver:
             max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
             first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin), margins=margins,
             dense_columns=int(r.dense_columns), refactors=int(r.refactors))
+
+    def set_profile(self, mask: int) -> None:
+        """Which kernel classes (bits 1 << _ffi.K_*) the following runs time with HIP events."""
+        _ffi.check(_ffi.lib().dzg_solver_set_profile(self._h, int(mask)), "dzg_solver_set_profile")
 
     def refactor(self) -> None:
         """FAST: rebuild the basis inverse from scratch now (blocked LU + MFMA GEMMs)."""

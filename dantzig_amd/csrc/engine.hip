@@ -482,14 +482,12 @@ struct Prof {
 
 static int price_kernel_for(const dzg_solver *s)
 {
-    // AUTO: the sequential-order kernel (bit-identical sums) while every wave of its grid gets
-    // >= 12 columns -- above that it streams at the HBM rate; its serial additions cost
-    // ~120 us per 8192 rows however few columns there are, so smaller column sets (small LPs,
-    // column shards) take the tree-order kernel.
+    // AUTO: FAST numerics streams with the register-accumulator kernel, whose sums depend only
+    // on m (bit-identical dz on one GPU and on any column sharding); the reference-order kernel
+    // (bit-identical to neg_t_dot) belongs to STRICT, whose v is the reference's v.
     if (s->d.csc) return DZG_PRICE_CSC_KERNEL;
     if (s->opts.price_kernel != DZG_PRICE_AUTO) return s->opts.price_kernel;
-    const long long local_cols = (long long)s->d.col1 - s->d.col0;
-    return local_cols >= 12ll * 1024 ? DZG_PRICE_SEQ : DZG_PRICE_WAVE;
+    return DZG_PRICE_TREE;
 }
 
 static void enqueue_fast_iteration(dzg_solver *s, int slot)
@@ -544,6 +542,7 @@ static void collect_profile(dzg_solver *s, int slots_real)
                 s->kernel_launches[cls] += 1;
             }
         }
+    (void)hipGetLastError(); // a class this numerics mode never stamps (e.g. DZG_K_LU in FAST)
 }
 
 static int read_ctl(dzg_solver *s)
@@ -766,6 +765,15 @@ extern "C" int dzg_solver_set_budget(dzg_solver *s, int64_t max_new_iters)
     if (!s) return fail(DZG_E_ARG, "solver is NULL");
     HIP_OK(hipSetDevice(s->opts.device));
     return set_budget(s, max_new_iters);
+}
+
+extern "C" int dzg_solver_set_profile(dzg_solver *s, int32_t mask)
+{
+    if (!s) return fail(DZG_E_ARG, "solver is NULL");
+    if (mask != 0 && s->ev.empty())
+        return fail(DZG_E_ARG, "kernel timing needs opts.profile != 0 at creation (it reserves the events)");
+    s->opts.profile = mask;
+    return 0;
 }
 
 extern "C" int dzg_solver_poll(dzg_solver *s, int32_t *status, int64_t *iterations)

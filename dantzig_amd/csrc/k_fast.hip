@@ -181,7 +181,14 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         if (cj.k >= 0 && ci.k >= 0) {
             const double primal = ci.r, dual = cj.r;
             const double top = primal > dual ? primal : dual;
-            margin = fabs(top - eps);
+            // eps is an absolute threshold at rounding level itself: the test is inside the
+            // tolerance when `top` is within eps/2 of it, or within what the health monitor says
+            // FAST's rounding amounts to (a degenerate optimum has top = 0 up to that rounding
+            // in FAST and exactly in the reference: both sides of the test agree)
+            const double noise = 64.0 * c.max_pivot_err;
+            const double tau_opt = noise > 0.5 * eps ? noise : 0.5 * eps;
+            margin = fabs(top - eps) > tau_opt ? inf : 0.0;
+            if (c.tie_tol < 0.0) margin = inf;
             if (primal <= eps && dual <= eps) {
                 verdict = DZG_OPTIMAL;
             } else {

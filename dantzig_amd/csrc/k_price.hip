@@ -1,15 +1,43 @@
 // k_price.hip -- launchers of the pricing kernels (kernels and design notes: k_price_kernels.h)
 #include "k_price_kernels.h"
 
-static int resolve(int kernel) { return kernel == DZG_PRICE_WAVE ? DZG_PRICE_WAVE : DZG_PRICE_SEQ; }
+static int resolve(int kernel)
+{
+    return kernel == DZG_PRICE_WAVE || kernel == DZG_PRICE_TREE ? kernel : DZG_PRICE_SEQ;
+}
 
-static void launch(int kernel, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
+#define PRICE_ARGS ctl, A, lda, m, q, plist, nonbasis, var_col, v, dz, z, zbar, rz_r, rz_k, rz_h, col0
+
+// the tree kernel's sums do not depend on its shape: pick columns-per-wave x tiles-in-flight
+// from the number of columns a wave will get at most (ncols is an upper bound of the count)
+static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
+                        const int *plist, const int *nonbasis, const int *var_col, const double *v,
+                        double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
+                        double *rz_h, int col0, hipStream_t st)
+{
+    const dim3 grid(DZG_PRICE_TREE_BLOCKS), block(256);
+    const int per_wave = (ncols + 4 * DZG_PRICE_TREE_BLOCKS - 1) / (4 * DZG_PRICE_TREE_BLOCKS);
+    if (per_wave > 8)
+        hipLaunchKernelGGL((k_price_tree<16, 2>), grid, block, 0, st, PRICE_ARGS);
+    else if (per_wave > 4)
+        hipLaunchKernelGGL((k_price_tree<8, 4>), grid, block, 0, st, PRICE_ARGS);
+    else if (per_wave > 2)
+        hipLaunchKernelGGL((k_price_tree<4, 8>), grid, block, 0, st, PRICE_ARGS);
+    else if (per_wave > 1)
+        hipLaunchKernelGGL((k_price_tree<2, 16>), grid, block, 0, st, PRICE_ARGS);
+    else
+        hipLaunchKernelGGL((k_price_tree<1, 32>), grid, block, 0, st, PRICE_ARGS);
+}
+
+static void launch(int kernel, int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
                    const int *plist, const int *nonbasis, const int *var_col, const double *v,
                    double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
                    double *rz_h, int col0, hipStream_t st)
 {
     if (q <= 0) return;
-    if (resolve(kernel) == DZG_PRICE_WAVE)
+    if (resolve(kernel) == DZG_PRICE_TREE)
+        launch_tree(ncols, PRICE_ARGS, st);
+    else if (resolve(kernel) == DZG_PRICE_WAVE)
         hipLaunchKernelGGL((k_price_wave2<4>), dim3(DZG_PRICE_WAVE_BLOCKS), dim3(256), 0, st, ctl, A,
                            lda, m, q, plist, nonbasis, var_col, v, dz, z, zbar, rz_r, rz_k, rz_h, col0);
     else
@@ -21,6 +49,7 @@ static void launch(int kernel, const DzgCtl *ctl, const double *A, long long lda
 int dzg_price_partials(int kernel)
 {
     if (kernel == DZG_PRICE_CSC_KERNEL) return DZG_PRICE_CSC_BLOCKS;
+    if (resolve(kernel) == DZG_PRICE_TREE) return DZG_PRICE_TREE_BLOCKS;
     return resolve(kernel) == DZG_PRICE_WAVE ? DZG_PRICE_WAVE_BLOCKS : DZG_PRICE_SEQ_BLOCKS;
 }
 
@@ -40,7 +69,7 @@ void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
         launch_csc(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
         return;
     }
-    launch(kernel, d.ctl, d.A, d.lda, d.m, d.q, nullptr, d.nonbasis, d.var_col, d.v, d.dz, nullptr,
+    launch(kernel, d.q, d.ctl, d.A, d.lda, d.m, d.q, nullptr, d.nonbasis, d.var_col, d.v, d.dz, nullptr,
            nullptr, nullptr, nullptr, nullptr, 0, st);
 }
 
@@ -51,13 +80,13 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
         launch_csc(d, d.plist, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, st);
         return;
     }
-    launch(kernel, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nonbasis, d.var_col, d.v, d.dz, d.z,
+    launch(kernel, d.col1 - d.col0, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nonbasis, d.var_col, d.v, d.dz, d.z,
            d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, st);
 }
 
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st)
 {
-    launch(kernel, nullptr, A, lda, m, ncols, nullptr, cols, nullptr, v, out, nullptr, nullptr,
+    launch(kernel, ncols, nullptr, A, lda, m, ncols, nullptr, cols, nullptr, v, out, nullptr, nullptr,
            nullptr, nullptr, nullptr, 0, st);
 }

@@ -340,6 +340,128 @@ __global__ __launch_bounds__(256) void k_price_wave2(
 }
 
 // ---------------------------------------------------------------------------------
+// k_price_tree<CW, DEPTH>: the FAST-numerics pricing kernel.  Same streaming skeleton as
+// k_price_seq2 -- a wave owns CW columns at a time, 1-KiB fully coalesced nontemporal loads per
+// column and 128-row tile, DEPTH tiles in flight in registers, exact s_waitcnt counts -- but the
+// sums stay in registers: lane l keeps ONE accumulator per column and adds its two rows of every
+// tile with fma, tiles ascending; 64 partial sums per column are folded by an xor-shuffle tree at
+// the end.  No LDS, no serial chain, so nothing but HBM bounds it, whatever the column count.
+//
+// The summation order of a column depends only on m -- not on CW, DEPTH, the grid or which wave
+// gets the column -- so dz is bit-identical between a single GPU and any column sharding: the
+// sharded solve takes the same pivots as the unsharded one.  (FAST's v comes from the explicit
+// inverse and is not bit-identical to the reference's anyway; the reference-order sums of
+// k_price_seq2 matter for STRICT numerics only.)
+// ---------------------------------------------------------------------------------
+template <int CW, int DEPTH>
+__global__ __launch_bounds__(256) void k_price_tree(
+    const DzgCtl *ctl, const double *__restrict__ A, long long lda, int m, int q,
+    const int *__restrict__ plist, const int *__restrict__ nonbasis,
+    const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
+    const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
+    int *__restrict__ rz_k, double *__restrict__ rz_h, int col0 = 0)
+{
+    constexpr int TR = 128;
+    if (ctl && ctl->status != DZG_RUNNING) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const int wg = blockIdx.x * 4 + wave;
+    const double mu = ctl ? ctl->mu : 0.0, tau = ctl ? ctl->tau : 0.0;
+    DzgCand2 best = dzg_cand2_none();
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, tau, z, zbar);
+
+    const int count = plist ? (int)ctl->nb_struct : q;
+    const int base = count / nw, rem = count % nw;
+    const int start = wg * base + (wg < rem ? wg : rem);
+    const int cnt = base + (wg < rem ? 1 : 0);
+    const int ntiles = (m + TR - 1) / TR;
+    const int lastpair = (int)lda - 2;
+    const int lastv = ((m + 1) & ~1) - 2 >= 0 ? ((m + 1) & ~1) - 2 : 0;
+
+    for (int c0 = 0; c0 < cnt; c0 += CW) {
+        const int nc = (cnt - c0) < CW ? (cnt - c0) : CW;
+        int mypos = -1, mycode = -1;
+        if (lane < nc) {
+            const int idx = start + c0 + lane;
+            mypos = plist ? plist[idx] : idx;
+            mycode = price_code(nonbasis, var_col, mypos);
+        }
+        // wave-uniform column offsets; every load is unconditional (columns past nc and unit
+        // columns re-read the wave's last valid column and are ignored), see k_price_seq2
+        int lastcode = col0;
+#pragma unroll
+        for (int l = 0; l < CW; ++l) {
+            const int code_l = __builtin_amdgcn_readlane(mycode, l);
+            if (code_l >= 0) lastcode = code_l;
+        }
+        long long off[CW];
+#pragma unroll
+        for (int l = 0; l < CW; ++l) {
+            const int code_l = __builtin_amdgcn_readlane(mycode, l);
+            off[l] = (long long)((code_l >= 0 ? code_l : lastcode) - col0) * lda;
+        }
+        double2_t rg[DEPTH][CW], vg[DEPTH];
+        double acc[CW];
+#pragma unroll
+        for (int l = 0; l < CW; ++l) acc[l] = 0.0;
+
+        auto fetch = [&](int t, double2_t(&reg)[CW], double2_t &vreg) {
+            const int row = t * TR + 2 * lane;
+            const int rowc = row < lda ? row : lastpair;
+#pragma unroll
+            for (int l = 0; l < CW; ++l)
+                reg[l] = __builtin_nontemporal_load(
+                    reinterpret_cast<const double2_t *>(A + off[l] + rowc));
+            vreg = *reinterpret_cast<const double2_t *>(v + (row < m ? row : lastv));
+        };
+        // rows >= m: the matrix holds zeros (padding) or, clamped, a repeated pair -- masked
+        auto consume = [&](int t, const double2_t(&reg)[CW], const double2_t &vreg) {
+            const bool inside = t * TR + 2 * lane < m; // v carries zero pads past m
+#pragma unroll
+            for (int l = 0; l < CW; ++l) {
+                const double ax = inside ? reg[l].x : 0.0, ay = inside ? reg[l].y : 0.0;
+                acc[l] = fma(ax, vreg.x, acc[l]);
+                acc[l] = fma(ay, vreg.y, acc[l]);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d < ntiles ? d : ntiles - 1, rg[d], vg[d]);
+        int t = 0;
+        for (; t + 2 * DEPTH - 1 < ntiles; t += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                consume(t + d, rg[d], vg[d]);
+                fetch(t + DEPTH + d, rg[d], vg[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (t + d < ntiles) {
+                consume(t + d, rg[d], vg[d]);
+                if (t + DEPTH + d < ntiles) fetch(t + DEPTH + d, rg[d], vg[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (t + DEPTH + d < ntiles) consume(t + DEPTH + d, rg[d], vg[d]);
+        // fold the 64 partial sums of every column; lane l keeps column l's total
+        double mine = 0.0;
+#pragma unroll
+        for (int l = 0; l < CW; ++l) {
+            double s = acc[l];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, DZG_WAVE);
+            if (lane == l) mine = s;
+        }
+        if (lane < nc && mycode >= 0) {
+            dz[mypos] = -mine;
+            if (z) price_candidate(best, -mine, mypos, mu, tau, z, zbar);
+        }
+    }
+    price_publish(best, rz_r, rz_k, rz_h);
+}
+
+// ---------------------------------------------------------------------------------
 // k_price_csc: sparse columns (CSC, rows ascending).  One thread per column walks its stored
 // entries in order: acc = acc + val * (-v[row]) -- literally the reference's neg_t_dot
 // (src/linalg.rs:199-207), so dz is bit-identical.  ~50 entries per column at config 4: the
@@ -405,3 +527,4 @@ __global__ __launch_bounds__(256) void k_price_csc(
 #define DZG_PRICE_CSC_BLOCKS 2048
 #define DZG_PRICE_SEQ_BLOCKS 256   // x 4 waves: one workgroup per CU
 #define DZG_PRICE_WAVE_BLOCKS 2048 // x 4 waves
+#define DZG_PRICE_TREE_BLOCKS 256  // x 4 waves

@@ -73,7 +73,11 @@ typedef enum {
     DZG_PRICE_AUTO = 0,
     DZG_PRICE_SEQ = 1,   /* one lane per column through an LDS-transposed tile: sums in the
                             reference's ascending-row order, bit-identical to neg_t_dot     */
-    DZG_PRICE_WAVE = 2   /* one wave per column, lane-strided partial sums + shuffle tree   */
+    DZG_PRICE_WAVE = 2,  /* one wave per column, lane-strided partial sums + shuffle tree   */
+    DZG_PRICE_TREE = 3   /* several columns per wave, register accumulators + shuffle tree: the
+                            streaming kernel of FAST numerics; sums depend only on m, so dz is
+                            bit-identical across column shardings (AUTO picks it for FAST and
+                            DZG_PRICE_SEQ for STRICT)                                         */
 } dzg_price_kernel;
 
 /* The LP in the state `Simplex::new` produces (src/simplex.rs:209-223):
@@ -358,6 +362,9 @@ int dzg_shard_run(dzg_solver *s, int64_t max_new_iters);
  * This is how the sharded device path is exercised on a single-GPU box. */
 int dzg_shard_run_lockstep(dzg_solver **solvers, int32_t world, int64_t max_new_iters);
 void *dzg_solver_stream(dzg_solver *s);
+/* Changes which kernel classes are timed (opts.profile mask) between runs; the solver must have
+ * been created with opts.profile != 0. */
+int dzg_solver_set_profile(dzg_solver *s, int32_t mask);
 /* Synchronises the stream and reads the status word and the pivot count. */
 int dzg_solver_poll(dzg_solver *s, int32_t *status, int64_t *iterations);
 /* Sets the run budget like dzg_solver_run does, without running (sharded hosts drive the loop). */

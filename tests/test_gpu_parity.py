@@ -605,3 +605,124 @@ def test_whole_solve_from_csc_follows_the_oracle_pivot_log(core):
     assert np.array_equal(np.array([p[1] for p in got.pivots]), fx["entering"])
     assert np.array_equal(np.array([p[2] for p in got.pivots]), fx["leaving"])
     assert np.array_equal(got.basis, fx["basis"])
+
+
+# ------------------------------------------------------------------ FAST near-tie arbitration
+def _integer_fixture():
+    import json
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "integer_lps_200_400.json")) as f:
+        return json.load(f)
+
+
+def test_auto_follows_the_oracle_on_integer_lps(core):
+    """200 small-integer and 0/1 LPs of 200-400 rows (exact ties, 0/0 and x/0 ratios: the data on
+    which FAST numerics used to leave the reference's path without a signal) through
+    dzg_core_solve with AUTO numerics: status, pivot count and pivot log (sha256 of the
+    (kind, entering, leaving) triples) equal the committed CPU-oracle outcome on every one.
+    AUTO = FAST that stops at the first decision within rounding of a tie, then STRICT from the
+    first pivot (src/simplex.rs:423-461 is a strict first-wins argmax: only the reference's own
+    arithmetic can arbitrate a tie)."""
+    from tests.lp_families import log_digest, make_lp
+
+    fx = _integer_fixture()
+    bad, strict = [], 0
+    for case in fx["cases"]:
+        a, b, c = make_lp(case["seed"], case["kind"], fx["min_m"], fx["max_m"])
+        assert a.shape == (case["m"], case["ns"])
+        lp = core.CoreLP.from_inequality_form(a, b, c)
+        r = core.core_solve(lp, numerics=core.AUTO, max_iter=fx["cap"], log_cap=fx["cap"])
+        strict += r.numerics == "strict"
+        if (r.status, r.iterations, log_digest(r.pivots)) != (case["status"], case["pivots"],
+                                                              case["sha256"]):
+            bad.append((case["seed"], r.status, case["status"], r.iterations, case["pivots"],
+                        r.numerics))
+    assert not bad, bad
+    assert strict > 150  # these LPs are full of ties: nearly all must have been handed to STRICT
+
+
+def test_fast_leaves_the_oracle_path_only_where_it_flagged_a_near_tie(core):
+    """FAST with near ties COUNTED (no stop) on 150 small LPs of all three families: wherever its
+    pivot log or verdict differs from the oracle's, a near tie was flagged at or before the first
+    differing pivot; on continuous data nothing is flagged and nothing differs."""
+    from tests.lp_families import log3, make_lp
+
+    unflagged, flagged_continuous = [], []
+    for seed in range(7000, 7150):
+        kind = seed % 3
+        a, b, c = make_lp(seed, kind, 1, 60)
+        want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=5000)
+        lp = core.CoreLP.from_inequality_form(a, b, c)
+        f = core.solve(lp, numerics=core.FAST, max_iter=5000, poll_interval=8)
+        got, wlog = log3(f.pivots), log3(want.pivots)
+        if kind == 0 and (f.near_ties or got != wlog or f.status != want.status):
+            flagged_continuous.append((seed, f.near_ties, f.status, want.status))
+        if got != wlog or f.status != want.status:
+            d = next((i for i, (p, q) in enumerate(zip(got, wlog)) if p != q),
+                     min(len(got), len(wlog)))
+            if not 0 <= f.first_near_tie <= d:
+                unflagged.append((seed, kind, f.status, want.status, d, f.first_near_tie))
+    assert not unflagged, unflagged
+    assert not flagged_continuous, flagged_continuous
+
+
+def test_near_tie_stop_is_resumable(core):
+    """opts.near_tie_action = STOP ends the run BEFORE the ambiguous pivot with DZG_NEAR_TIE, the
+    state being that of the last executed pivot (a prefix of the oracle's log); running again
+    takes the decision as FAST sees it and counts it."""
+    from tests.lp_families import log3, make_lp
+
+    a, b, c = make_lp(7001, 1, 30, 40)  # small integers: ties from the first pivot on
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=2000)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    with core.Solver(lp, numerics=core.FAST, near_tie_action=core.NEAR_TIE_STOP,
+                     max_iter=2000) as s:
+        assert s.run(0) == "near_tie"
+        r = s.result()
+        assert r.status == "near_tie" and r.near_ties == 0
+        assert log3(r.pivots) == log3(want.pivots)[:r.iterations]
+        stops = 0
+        while s.run(0) == "near_tie":
+            stops += 1
+            assert stops < 2000
+        r2 = s.result()
+    assert r2.near_ties >= 1 and r2.first_near_tie == r.iterations
+    assert r2.iterations > r.iterations or r2.status != "near_tie"
+    assert len(r2.margins) == len(r2.pivots) and r2.min_margin <= r2.margins.min()
+
+
+def test_continuous_lp_is_not_flagged(core):
+    """BASELINE config 2's family at 512 x 1024: thousands of pivots on continuous data, the
+    oracle's log taken pivot for pivot, no near tie met -- AUTO keeps FAST's answer."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_pivots_2001_512x1024.npz"))
+    a, b, c = core.gen_dense_lp(seed=int(fx["seed"]), m=int(fx["m"]), n_struct=int(fx["n_struct"]))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    r = core.core_solve(lp, numerics=core.AUTO, log_cap=1 << 14)
+    assert r.numerics == "fast" and r.status == "optimal" and r.near_ties == 0
+    assert r.iterations == int(fx["iterations"]) and r.min_margin > 1e-11
+    assert np.array_equal(np.array([p[1] for p in r.pivots]), fx["entering"])
+
+
+# ------------------------------------------------------------------ k_price_tree
+def test_tree_pricing_does_not_depend_on_its_launch_shape(core):
+    """k_price_tree's sums depend only on m: the same column priced among 5, 700, 3000 or all
+    9000 columns (1, 2, 4, 8, 16 columns per wave; 32 ... 2 tiles in flight) gives the same bits --
+    which is what makes a column-sharded solve take the pivots of the unsharded one."""
+    rng = np.random.default_rng(5)
+    m, ns = 1000, 9000
+    a = rng.uniform(-1, 1, (m, ns))
+    v = rng.uniform(-1, 1, m)
+    full = core.neg_t_dot(a, np.arange(ns), v, kernel=core.PRICE_TREE)
+    assert np.allclose(full, -(a.T @ v), rtol=0, atol=1e-12)
+    for count in (5, 700, 1500, 3000, 5000):
+        cols = rng.choice(ns, count, replace=False)
+        part = core.neg_t_dot(a, cols, v, kernel=core.PRICE_TREE)
+        assert_bit_equal(part, full[cols], f"{count} columns")
+    # unit (slack) columns and a ragged row count
+    m2 = 333
+    a2 = rng.uniform(-1, 1, (m2, 40))
+    v2 = rng.uniform(-1, 1, m2)
+    cols2 = np.array([3, -1, 17, -m2, 39, -5])
+    got = core.neg_t_dot(a2, cols2, v2, kernel=core.PRICE_TREE)
+    want = np.array([-(a2[:, j] @ v2) if j >= 0 else -v2[-1 - j] for j in cols2])
+    assert np.allclose(got, want, rtol=0, atol=1e-13)

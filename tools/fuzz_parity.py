@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from dantzig_amd import core
 from oracle import oracle as ora
+from tests.lp_families import log3, make_lp
 
 
 def same_bits(x, y):
@@ -23,27 +24,6 @@ def same_bits(x, y):
     x, y = np.asarray(x, float), np.asarray(y, float)
     return x.shape == y.shape and bool(np.all((x.view(np.int64) == y.view(np.int64))
                                               | ((x == 0) & (y == 0)) | (np.isnan(x) & np.isnan(y))))
-
-
-def make_lp(seed, kind, min_m, max_m):
-    rng = np.random.default_rng(seed)
-    m, ns = int(rng.integers(min_m, max_m)), int(rng.integers(min_m, 2 * max_m))
-    if kind == 0:
-        a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
-        a = np.array(a)
-    elif kind == 1:  # small integers, many zeros: ties everywhere
-        a = rng.integers(-3, 4, (m, ns)).astype(np.float64)
-        b = rng.integers(-2, 9, m).astype(np.float64)
-        c = rng.integers(-4, 5, ns).astype(np.float64)
-    else:            # 0/1 matrix, nonnegative rhs: degenerate primal vertices
-        a = (rng.uniform(size=(m, ns)) < 0.3).astype(np.float64)
-        b = rng.integers(0, 4, m).astype(np.float64)
-        c = rng.integers(-1, 6, ns).astype(np.float64)
-    return a, b, c
-
-
-def log3(pivots):
-    return [(k, e, l) for k, e, l, _ in pivots]
 
 
 def first_difference(p, q):
