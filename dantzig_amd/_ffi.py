@@ -33,7 +33,7 @@ EXPORTS = [
     "dzg_shard_record_doubles", "dzg_shard_phase1", "dzg_shard_phase2", "dzg_shard_phase3",
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
-    "dzg_gen_dense_lp_block", "dzg_solver_set_profile",
+    "dzg_gen_dense_lp_block", "dzg_solver_set_profile", "dzg_kernel_neg_t_dot_csc",
 ]
 
 

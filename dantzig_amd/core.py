@@ -327,6 +327,19 @@ def neg_t_dot(a: np.ndarray, cols, v, kernel: int = PRICE_SEQ, device: int = 0) 
     return out[: len(cols)]
 
 
+def neg_t_dot_csc(m: int, col_ptr, row_idx, val, cols, v, device: int = 0) -> np.ndarray:
+    """neg_t_dot over a CSC matrix kept sparse on the device (k_price_csc)."""
+    _ffi.require_gpu()
+    col_ptr, cols, v, val = i64(col_ptr), i64(cols), f64(v), f64(val)
+    row_idx = np.ascontiguousarray(row_idx, dtype=np.int32)
+    out = np.empty(max(len(cols), 1))
+    rc = _ffi.lib().dzg_kernel_neg_t_dot_csc(
+        C.c_int64(m), C.c_int64(len(col_ptr) - 1), ptr(col_ptr), ptr(row_idx), ptr(val), ptr(cols),
+        C.c_int64(len(cols)), ptr(v), ptr(out), C.c_int32(device))
+    _ffi.check(rc, "dzg_kernel_neg_t_dot_csc")
+    return out[: len(cols)]
+
+
 def first_pivot(y, ybar, device: int = 0) -> int:
     _ffi.require_gpu()
     y, ybar = f64(y), f64(ybar)

@@ -349,6 +349,9 @@ int dzg_price_partials(int kernel);
 #define DZG_PRICE_CSC_KERNEL 100 // internal id: the CSC pricing kernel
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st);
+void dzg_launch_price_csc_raw(const long long *cptr, const int *ridx, const double *cval,
+                              const int *cols, int ncols, const double *v, double *out,
+                              hipStream_t st);
 
 // k_strict.hip
 // solves  B y = rhs  (transposed == 0, rhs = d.acol -> d.dx)  or

@@ -593,6 +593,7 @@ static int refactor_now(dzg_solver *s)
     dzg_launch_refactor(d, counts[0], counts[1], s->rfG, s->rfX, s->rf_ld, s->rf_piv, s->rf_spos,
                         s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_lslot, s->rf_counts + 2, s->st);
     s->since_flush = 0;
+    s->h_ctl->neta = 0; // the refactorisation empties the eta file (k_ref_done)
     s->since_refactor = 0;
     s->refactors += 1;
     return 0;
@@ -629,13 +630,32 @@ static int health_stop(dzg_solver *s)
     return 0;
 }
 
+// Budget spent: the host ends the run itself instead of enqueueing an iteration that would only
+// discover it (a no-op iteration would still advance the host's flush bookkeeping, and the eta
+// flush must fall after the same pivots however a solve is cut into runs: results are
+// reproducible bit for bit across budgets, poll intervals and near-tie stops).
+static int budget_spent(dzg_solver *s, bool *spent)
+{
+    *spent = s->h_ctl->status == DZG_RUNNING && s->h_ctl->iter >= s->h_ctl->iter_stop;
+    if (*spent) {
+        int st = DZG_ITER_LIMIT;
+        HIP_OK(hipMemcpy(&s->d.ctl->status, &st, sizeof(int), hipMemcpyHostToDevice));
+        s->h_ctl->status = st;
+    }
+    return 0;
+}
+
 static int run_fast(dzg_solver *s)
 {
     for (;;) {
+        bool spent = false;
+        TRY(budget_spent(s, &spent));
+        if (spent) break;
         if (s->opts.refactor_interval > 0 && s->since_refactor >= s->opts.refactor_interval)
             TRY(refactor_now(s));
         const long long before = s->h_ctl->iter;
         const int batch = batch_size(s);
+        s->since_flush = s->h_ctl->neta; // pending etas as the device counts them
         if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
             TRY(shard_buffers(s));
             const size_t nb = sizeof(double) * (size_t)s->d.xstride;
@@ -890,8 +910,12 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
     const size_t n = (size_t)s->d.xstride;
     auto t0 = std::chrono::steady_clock::now();
     for (;;) {
+        bool spent = false;
+        TRY(budget_spent(s, &spent));
+        if (spent) break;
         const long long before = s->h_ctl->iter;
         const int batch = batch_size(s);
+        s->since_flush = s->h_ctl->neta;
         for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
@@ -937,7 +961,11 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         return 0;
     };
     for (;;) {
+        bool spent = false;
+        for (int r = 0; r < world; ++r) TRY(budget_spent(sv[r], &spent));
+        if (spent) break;
         const int batch = batch_size(sv[0]);
+        for (int r = 0; r < world; ++r) sv[r]->since_flush = sv[r]->h_ctl->neta;
         for (int b = 0; b < batch; ++b) {
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));
             TRY(exchange(false));
@@ -1167,6 +1195,50 @@ extern "C" int dzg_kernel_neg_t_dot(int64_t m, int64_t n_struct, const double *a
     HIP_OK(hipGetLastError());
     if (ncols > 0) HIP_OK(hipMemcpy(out, dout, sizeof(double) * ncols, hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dv); hipFree(dout); hipFree(dcols);
+    return 0;
+}
+
+extern "C" int dzg_kernel_neg_t_dot_csc(int64_t m, int64_t n_struct, const int64_t *col_ptr,
+                                        const int32_t *row_idx, const double *val,
+                                        const int64_t *cols, int64_t ncols, const double *v,
+                                        double *out, int32_t device)
+{
+    if (m <= 0 || n_struct < 0 || ncols < 0 || !v || !out || (ncols > 0 && !cols) || !col_ptr ||
+        col_ptr[0] != 0 || (n_struct > 0 && col_ptr[n_struct] > 0 && (!row_idx || !val)))
+        return fail(DZG_E_ARG, "bad argument");
+    if (dzg_device_count() <= 0) return fail(DZG_E_DEVICE, "no HIP device visible");
+    HIP_OK(hipSetDevice(device));
+    const size_t nnz = (size_t)col_ptr[n_struct];
+    for (int64_t j = 0; j < n_struct; ++j)
+        for (int64_t e = col_ptr[j]; e < col_ptr[j + 1]; ++e)
+            if (row_idx[e] < 0 || row_idx[e] >= m) return fail(DZG_E_ARG, "row_idx out of range");
+    std::vector<long long> cp((size_t)n_struct + 1);
+    for (int64_t j = 0; j <= n_struct; ++j) cp[(size_t)j] = col_ptr[j];
+    std::vector<int> c32((size_t)(ncols ? ncols : 1));
+    for (int64_t k = 0; k < ncols; ++k) {
+        if (cols[k] >= n_struct || cols[k] < -m) return fail(DZG_E_ARG, "cols out of range");
+        c32[(size_t)k] = (int)cols[k];
+    }
+    long long *dcp; int *dri, *dcols; double *dcv, *dv, *dout;
+    HIP_OK(hipMalloc(&dcp, sizeof(long long) * cp.size()));
+    HIP_OK(hipMalloc(&dri, sizeof(int) * (nnz + 1)));
+    HIP_OK(hipMalloc(&dcv, sizeof(double) * (nnz + 1)));
+    HIP_OK(hipMalloc(&dv, sizeof(double) * ((size_t)m + 2)));
+    HIP_OK(hipMalloc(&dout, sizeof(double) * c32.size()));
+    HIP_OK(hipMalloc(&dcols, sizeof(int) * c32.size()));
+    HIP_OK(hipMemcpy(dcp, cp.data(), sizeof(long long) * cp.size(), hipMemcpyHostToDevice));
+    if (nnz) {
+        HIP_OK(hipMemcpy(dri, row_idx, sizeof(int) * nnz, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dcv, val, sizeof(double) * nnz, hipMemcpyHostToDevice));
+    }
+    HIP_OK(hipMemset(dv, 0, sizeof(double) * ((size_t)m + 2)));
+    HIP_OK(hipMemcpy(dv, v, sizeof(double) * m, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dcols, c32.data(), sizeof(int) * c32.size(), hipMemcpyHostToDevice));
+    dzg_launch_price_csc_raw(dcp, dri, dcv, dcols, (int)ncols, dv, dout, 0);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipGetLastError());
+    if (ncols > 0) HIP_OK(hipMemcpy(out, dout, sizeof(double) * ncols, hipMemcpyDeviceToHost));
+    hipFree(dcp); hipFree(dri); hipFree(dcv); hipFree(dv); hipFree(dout); hipFree(dcols);
     return 0;
 }
 

@@ -90,3 +90,17 @@ void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, con
     launch(kernel, ncols, nullptr, A, lda, m, ncols, nullptr, cols, nullptr, v, out, nullptr, nullptr,
            nullptr, nullptr, nullptr, 0, st);
 }
+
+// CSC twin of dzg_launch_price_raw: cols[k] >= 0 is a stored column, < 0 the unit column of row
+// -1 - cols[k]; no control block, no ratio test.
+void dzg_launch_price_csc_raw(const long long *cptr, const int *ridx, const double *cval,
+                              const int *cols, int ncols, const double *v, double *out,
+                              hipStream_t st)
+{
+    if (ncols <= 0) return;
+    hipLaunchKernelGGL(k_price_csc, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st,
+                       (const DzgCtl *)nullptr, cptr, ridx, cval, ncols, (const int *)nullptr, cols,
+                       (const int *)nullptr, v, out, (const double *)nullptr,
+                       (const double *)nullptr, (double *)nullptr, (int *)nullptr,
+                       (double *)nullptr, 0);
+}

@@ -294,6 +294,13 @@ int dzg_kernel_neg_t_dot(int64_t m, int64_t n_struct, const double *a, int64_t l
                          const int64_t *cols, int64_t ncols, const double *v, double *out,
                          int32_t kernel, int32_t device);
 
+/* The same on a CSC matrix (the reference's own storage, src/linalg.rs:161-168: rows ascending
+ * inside a column, no explicit zeros): out[k] = sum over the stored entries of column cols[k],
+ * in stored order, of val * -v[row] -- exactly neg_t_dot's loop (src/linalg.rs:199-207). */
+int dzg_kernel_neg_t_dot_csc(int64_t m, int64_t n_struct, const int64_t *col_ptr,
+                             const int32_t *row_idx, const double *val, const int64_t *cols,
+                             int64_t ncols, const double *v, double *out, int32_t device);
+
 /* find_first_pivot (src/simplex.rs:423-437): position or -1. */
 int dzg_kernel_first_pivot(int64_t len, const double *y, const double *ybar, int64_t *pos_out,
                            int32_t device);

@@ -107,3 +107,132 @@ def test_whole_solve_is_certified_optimal_by_lapack(core, seed, m, ns):
     assert cert["primal_infeas"] <= 1e-9 and cert["dual_infeas"] <= 1e-9
     assert abs(cert["primal_obj"] - cert["dual_obj"]) <= 1e-9 * scale
     assert abs(res.objective - cert["primal_obj"]) <= 1e-9 * scale
+
+
+# ------------------------------------------------------------------ BASELINE config 4
+# sparse 50 000 x 100 000, 50 nonzeros per column (0.1 %), generator G2 seed 1004, kept CSC
+M4, NS4, PER_COL4, SEED4 = 50_000, 100_000, 50, 1004
+
+
+@pytest.fixture(scope="module")
+def sparse_lp(core):
+    return core.gen_sparse_lp(SEED4, M4, NS4, PER_COL4)
+
+
+def test_config4_csc_pricing_is_the_reference_sum(core, sparse_lp):
+    """k_price_csc at config 4's size: dz of sampled columns equals, bit for bit, the
+    reference's loop -- stored entries in ascending-row order, product and sum rounded
+    separately (src/linalg.rs:199-207) -- written out in Python; the whole pass agrees with
+    scipy's CSC product to rounding; linear in v; unit columns exact."""
+    import scipy.sparse as sp
+
+    cp, ri, val, _, _ = sparse_lp
+    assert cp[-1] == NS4 * PER_COL4 and np.all(np.diff(cp) == PER_COL4)
+    rng = np.random.default_rng(11)
+    v1, v2 = rng.uniform(-1, 1, M4), rng.uniform(-1, 1, M4)
+    cols = np.arange(NS4)
+    d1 = core.neg_t_dot_csc(M4, cp, ri, val, cols, v1)
+    for j in rng.choice(NS4, 200, replace=False):
+        acc = 0.0
+        for e in range(cp[j], cp[j + 1]):
+            assert e == cp[j] or ri[e] > ri[e - 1]          # rows ascend inside a column
+            acc = acc + val[e] * -v1[ri[e]]
+        assert d1[j] == acc
+    a = sp.csc_matrix((val, ri, cp), shape=(M4, NS4))
+    assert np.abs(d1 + a.T @ v1).max() <= 1e-13 * PER_COL4
+    d2 = core.neg_t_dot_csc(M4, cp, ri, val, cols, v2)
+    d12 = core.neg_t_dot_csc(M4, cp, ri, val, cols, v1 + v2)
+    assert np.abs(d12 - (d1 + d2)).max() <= 1e-13 * PER_COL4
+    mix = np.concatenate([rng.permutation(NS4)[:5000], -1 - rng.integers(0, M4, 64)])
+    dm = core.neg_t_dot_csc(M4, cp, ri, val, mix, v1)
+    assert np.array_equal(dm[:5000], d1[mix[:5000]])
+    assert np.array_equal(dm[5000:], 0.0 + -v1[-1 - mix[5000:]])
+
+
+def test_config4_fast_run_invariants(core, sparse_lp):
+    """1 000 pivots of FAST numerics on config 4 (matrix CSC on the device): basis / nonbasis stay
+    a partition, the basic solution the engine carries satisfies A x_B + slack = b under scipy's
+    arithmetic, the two computations of every pivot element agree, and the pricing pass moved
+    the bytes the roofline is priced on (12 B per stored entry of a nonbasic column)."""
+    import scipy.sparse as sp
+
+    cp, ri, val, b, c = sparse_lp
+    lp = core.CoreLP.from_csc(M4, cp, ri, val, b, c)
+    with core.Solver(lp, numerics=core.FAST, poll_interval=50) as s:
+        assert s.run(1000) == "iter_limit"
+        res = s.result()
+    assert res.iterations == 1000 and len(res.pivots) == 1000
+    both = np.concatenate([res.basis, res.nonbasis])
+    assert np.array_equal(np.sort(both), np.arange(NS4 + M4))
+    assert res.max_pivot_error < 1e-10
+    assert 0 < res.dense_columns <= 1000
+    xs, slack = np.zeros(NS4), np.zeros(M4)
+    for pos, var in enumerate(res.basis):
+        if var < NS4:
+            xs[var] = res.x[pos]
+        else:
+            slack[var - NS4] = res.x[pos]
+    a = sp.csc_matrix((val, ri, cp), shape=(M4, NS4))
+    assert np.abs(a @ xs + slack - b).max() <= 1e-9
+    per_launch = res.price_bytes / res.iterations
+    assert 12 * (NS4 - 1000) * PER_COL4 <= per_launch <= 12 * NS4 * PER_COL4 + 36 * NS4 + 8 * M4
+    # a budgeted continuation resumes the same trajectory: same log as an uninterrupted run
+    with core.Solver(lp, numerics=core.FAST, poll_interval=64) as s2:
+        assert s2.run(300) == "iter_limit" and s2.run(700) == "iter_limit"
+        again = s2.result()
+    assert again.pivots == res.pivots
+
+
+# ------------------------------------------------------------------ BASELINE config 5
+# dense 32768 x 65536, generator G1 seed 1005 -- on ONE GPU (16 GiB of matrix, 288 GB of HBM)
+M5, NS5, SEED5 = 32768, 65536, 1005
+
+
+@pytest.fixture(scope="module")
+def config5(core):
+    return core.gen_dense_lp(seed=SEED5, m=M5, n_struct=NS5)
+
+
+def test_config5_first_pivots_are_the_strict_log(core, config5):
+    """The first 80 pivots of config 5 equal the committed log of STRICT numerics -- the
+    reference's arithmetic -- for this LP (tests/golden/pivots_1005_32768x65536.json; STRICT needs
+    12.7 s per pivot here, profiles/r01_strict_vs_fast_32768x65536_80pivots.txt), no decision
+    came within the tie tolerance, and the run keeps the engine's invariants."""
+    import hashlib
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pivots_1005_32768x65536.json")) as f:
+        fx = json.load(f)
+    assert (fx["m"], fx["n_struct"], fx["seed"]) == (M5, NS5, SEED5)
+    a, b, c = config5
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    res = core.solve(lp, numerics=core.FAST, max_iter=fx["pivots"])
+    log = [(k, e, l) for k, e, l, _ in res.pivots]
+    assert log[:20] == list(zip(fx["kind"], fx["entering"], fx["leaving"]))[:20]
+    assert hashlib.sha256(repr(log).encode()).hexdigest() == fx["strict_sha256"]
+    assert np.allclose([p[3] for p in res.pivots], fx["mu_fast"], rtol=1e-12, atol=0)
+    assert res.near_ties == 0 and res.min_margin > 1e-9
+    assert res.max_pivot_error < 1e-12
+    assert np.array_equal(np.sort(np.concatenate([res.basis, res.nonbasis])), np.arange(NS5 + M5))
+
+
+def test_config5_pricing_pass_properties(core, config5):
+    """The streaming kernel at 32768 rows (256 tiles per column): against float64 numpy on
+    sampled columns, linear in v, independent of which other columns are priced with it."""
+    a = np.asarray(config5[0])[:, :13108]           # a 3.4 GB block: 13 108 columns, 16 per wave
+    rng = np.random.default_rng(12)
+    v1, v2 = rng.uniform(-1, 1, M5), rng.uniform(-1, 1, M5)
+    cols = np.arange(a.shape[1])
+    d1 = core.neg_t_dot(a, cols, v1, kernel=core.PRICE_TREE)
+    d2 = core.neg_t_dot(a, cols, v2, kernel=core.PRICE_TREE)
+    d12 = core.neg_t_dot(a, cols, v1 + v2, kernel=core.PRICE_TREE)
+    scale = np.sqrt(M5)
+    assert np.abs(d12 - (d1 + d2)).max() <= 1e-12 * scale * 10
+    pick = rng.choice(len(cols), 40, replace=False)
+    ref = -(np.asarray(a)[:, cols[pick]].T @ v1)
+    assert np.abs(d1[pick] - ref).max() <= 1e-12 * scale * 10
+    few = core.neg_t_dot(a, cols[pick], v1, kernel=core.PRICE_TREE)   # 1 column per wave
+    assert np.array_equal(few, d1[pick])
+    ds = core.neg_t_dot(a, cols[pick], v1, kernel=core.PRICE_SEQ)     # reference-order sums
+    assert np.abs(ds - d1[pick]).max() <= 1e-12 * scale * 10
