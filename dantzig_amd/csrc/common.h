@@ -56,6 +56,13 @@ struct DzgCtl {
     long long tie_skip_iter;  // stop mode: the iteration the host has acknowledged (resume)
     int tie_mode;         // 0: count and carry on, 1: stop with DZG_NEAR_TIE before the pivot
     int tie_seen;         // a decision of the pivot in flight was inside tau
+    // sparse-basis mode (k_sparse.hip): what k_sp_pivot booked for k_sp_update to move
+    int sp_k;             // k before this pivot
+    int sp_app;           // >= 0: row and column appended at this index
+    int sp_mrow;          // >= 0: row sp_k-1 of X moves into this row
+    int sp_mcol;          // >= 0: column sp_k-1 of X moves into this column
+    int sp_zcol;          // >= 0: column slot recycled for another row: cleared
+    int pad3;
 };
 
 // Partial-reduction fan-in sizes of the FAST pipeline (fixed grids => fixed counts)
@@ -310,6 +317,19 @@ struct DzgDev {
     int *fpx_k, *fpz_k, *rx_k, *rz_k;    // partial candidates (positions)
     double *fpx_h, *fpz_h, *rx_h, *rz_h; // partial candidates (runner-up ratios, DzgCand2::h)
     double *log_margin;                  // [log_cap] smallest decision margin of each pivot
+    // sparse-basis mode (spb != 0: CSC input on one GPU, k_sparse.hip): binv holds X = the k x k
+    // block of B^-1 (row b = structural basis position spos[b], column c = constraint row drow[c]),
+    // U and W the pending etas in the same compact numbering
+    int spb;
+    const long long *rptr; // CSR copy of the structural block: [m + 1]
+    const int *cidx;       // [nnz] column of each stored entry, ascending inside a row
+    const double *rval;    // [nnz]
+    int *sslot;            // [m]  row of X of basis position p, -1: a slack is basic there
+    int *spos;             // [m]  basis position of row b of X
+    int *bslot;            // [ns] row of X of structural column j when it is basic, else -1
+    int *rowpos;           // [m]  basis position of the slack of constraint row r, -1: nonbasic
+    double *dxs;           // [m]  dx on the structural positions, by row of X
+    int *acol_code;        // column code currently scattered in acol (INT_MIN: none)
     // strict numerics
     DzgLu lu;
     double eps;
@@ -375,3 +395,13 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
                          int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
                          int *singular, hipStream_t st);
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
+
+// k_sparse.hip
+void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st);
+void dzg_launch_sp_prep(const DzgDev &d, int mode, int nrz, hipStream_t st);
+void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, hipStream_t st);
+void dzg_launch_sp_btran(const DzgDev &d, hipStream_t st);
+void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st);
+void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st);
+void dzg_launch_sp_flush(const DzgDev &d, hipStream_t st);
+void dzg_launch_sp_ref_copy(const DzgDev &d, int k, const double *Xinv, long long ldx, hipStream_t st);

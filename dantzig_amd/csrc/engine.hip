@@ -304,6 +304,35 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             HIP_OK(hipMemcpy(dcv, cv.data(), sizeof(double) * cv.size(), hipMemcpyHostToDevice));
         }
         d.cptr = dcp; d.ridx = dri; d.cval = dcv;
+        // One GPU, FAST numerics: the basis lives on its k x k structural block (k_sparse.hip),
+        // which needs row access to the matrix as well: a CSR copy, columns ascending in a row.
+        const int want = o.numerics == DZG_NUMERICS_AUTO
+                             ? (m <= o.auto_strict_rows ? DZG_NUMERICS_STRICT : DZG_NUMERICS_FAST)
+                             : o.numerics;
+        if (d.world == 1 && want == DZG_NUMERICS_FAST && m <= (1 << 20)) {
+            d.spb = 1;
+            std::vector<long long> rp((size_t)m + 1, 0);
+            for (int r : ri) rp[(size_t)r + 1] += 1;
+            for (int r = 0; r < m; ++r) rp[(size_t)r + 1] += rp[(size_t)r];
+            std::vector<int> ci(ri.size());
+            std::vector<double> rv(ri.size());
+            std::vector<long long> fill(rp.begin(), rp.end() - 1);
+            for (int j = 0; j < nloc; ++j) // columns ascending => ascending inside every row
+                for (long long e = cp[(size_t)j]; e < cp[(size_t)j + 1]; ++e) {
+                    const long long at = fill[(size_t)ri[(size_t)e]]++;
+                    ci[(size_t)at] = j;
+                    rv[(size_t)at] = cv[(size_t)e];
+                }
+            long long *drp; int *dci; double *drv;
+            TRY(dev_alloc(s, &drp, rp.size())); TRY(dev_alloc(s, &dci, ci.size() + 1));
+            TRY(dev_alloc(s, &drv, rv.size() + 1));
+            HIP_OK(hipMemcpy(drp, rp.data(), sizeof(long long) * rp.size(), hipMemcpyHostToDevice));
+            if (!ci.empty()) {
+                HIP_OK(hipMemcpy(dci, ci.data(), sizeof(int) * ci.size(), hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(drv, rv.data(), sizeof(double) * rv.size(), hipMemcpyHostToDevice));
+            }
+            d.rptr = drp; d.cidx = dci; d.rval = drv;
+        }
     }
     // --- constraint matrix: column-major, zero-padded to lda rows (16-B aligned columns)
     double *A = nullptr;
@@ -436,8 +465,20 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.fpx_h, np)); TRY(dev_alloc(s, &d.fpz_h, np));
         TRY(dev_alloc(s, &d.rx_h, np)); TRY(dev_alloc(s, &d.rz_h, np));
         if (o.refactor_interval != 0) TRY(refactor_workspace(s));
+        if (d.spb) {
+            TRY(dev_alloc(s, &d.sslot, (size_t)m)); TRY(dev_alloc(s, &d.spos, (size_t)m));
+            TRY(dev_alloc(s, &d.bslot, (size_t)(ns ? ns : 1))); TRY(dev_alloc(s, &d.rowpos, (size_t)m));
+            TRY(dev_alloc(s, &d.dxs, (size_t)m)); TRY(dev_alloc(s, &d.acol_code, 1));
+            HIP_OK(hipMemsetAsync(d.acol, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
+            HIP_OK(hipMemsetAsync(d.dxs, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
+        }
         dzg_launch_fast_init(d, s->st);
-        dzg_launch_fast_update(d, 1, s->st); // first-pivot partials of the initial state
+        if (d.spb) {
+            dzg_launch_sp_init(d, 1, s->st);
+            dzg_launch_sp_update(d, 1, s->st);
+        } else {
+            dzg_launch_fast_update(d, 1, s->st); // first-pivot partials of the initial state
+        }
         if (needs_initial_refactor) {
             TRY(refactor_now(s));
         }
@@ -527,13 +568,47 @@ static void enqueue_fast_iteration(dzg_solver *s, int slot)
     }
 }
 
+// CSC input on one GPU: the sparse-basis kernels (k_sparse.hip).  Same phases as above.
+static void enqueue_sparse_iteration(dzg_solver *s, int slot)
+{
+    const DzgDev &d = s->d;
+    hipStream_t st = s->st;
+    Prof pf{s, slot};
+    pf.begin(DZG_K_STATUS);
+    dzg_launch_sp_prep(d, 0, 0, st);
+    pf.end(DZG_K_STATUS);
+    pf.begin(DZG_K_FTRAN);
+    dzg_launch_sp_ftran(d, DZG_STEP_PRIMAL, st);
+    pf.end(DZG_K_FTRAN);
+    pf.begin(DZG_K_BTRAN);
+    dzg_launch_sp_btran(d, st);
+    pf.end(DZG_K_BTRAN);
+    pf.begin(DZG_K_PRICE);
+    dzg_launch_price_fast(d, DZG_PRICE_CSC_KERNEL, st);
+    pf.end(DZG_K_PRICE);
+    pf.begin(DZG_K_RATIO);
+    dzg_launch_sp_prep(d, 1, dzg_price_partials(DZG_PRICE_CSC_KERNEL), st);
+    dzg_launch_sp_ftran(d, DZG_STEP_DUAL, st);
+    pf.end(DZG_K_RATIO);
+    pf.begin(DZG_K_UPDATE);
+    dzg_launch_sp_pivot(d, st);
+    dzg_launch_sp_update(d, 0, st);
+    pf.end(DZG_K_UPDATE);
+    pf.begin(DZG_K_BASIS_UPDATE);
+    if (++s->since_flush >= DZG_RMAX) {
+        dzg_launch_sp_flush(d, st); // X -= Ub^T Wc on the fp64 matrix cores
+        s->since_flush = 0;
+    }
+    pf.end(DZG_K_BASIS_UPDATE);
+}
+
 static void collect_profile(dzg_solver *s, int slots_real)
 {
     if (!s->opts.profile) return;
     for (int slot = 0; slot < slots_real; ++slot)
         for (int cls = 0; cls < DZG_K_COUNT; ++cls) {
             if (!(s->opts.profile & (1 << cls))) continue;
-            if ((s->d.csc || s->d.world > 1 || s->comm) && cls != DZG_K_PRICE)
+            if (((s->d.csc && !s->d.spb) || s->d.world > 1 || s->comm) && cls != DZG_K_PRICE)
                 continue; // the phase path only stamps pricing
             float ms = 0.f;
             size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
@@ -656,7 +731,9 @@ static int run_fast(dzg_solver *s)
         const long long before = s->h_ctl->iter;
         const int batch = batch_size(s);
         s->since_flush = s->h_ctl->neta; // pending etas as the device counts them
-        if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
+        if (s->d.spb) {
+            for (int b = 0; b < batch; ++b) enqueue_sparse_iteration(s, b);
+        } else if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
             TRY(shard_buffers(s));
             const size_t nb = sizeof(double) * (size_t)s->d.xstride;
             for (int b = 0; b < batch; ++b) {

@@ -394,6 +394,12 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
             if (j0 > 0) // X[0..j0) -= U01 * X1
                 gemm_sub(j0, k, nbw, G + j0, ldg, X + (long long)j0 * ldg, ldg, X, ldg, st);
         }
+        if (d.spb) {
+            // sparse-basis mode keeps the k x k block only (k_sparse.hip); rows in position order
+            dzg_launch_sp_ref_copy(d, k, X, ldg, st);
+            hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);
+            return;
+        }
         // ---- Binv0 rows of the structural positions
         hipLaunchKernelGGL(k_ref_scatter, dim3((k + 255) / 256, k), dim3(256), 0, st, k, X, ldg, spos,
                            d.binv, d.ldb);

@@ -1,0 +1,799 @@
+// k_sparse.hip -- FAST numerics for a constraint matrix kept sparse (CSC) on the device: the
+// basis is represented on its k x k structural block only, and FTRAN / BTRAN cost what the
+// sparse right-hand sides and the matrix's nonzeros cost, not 8*m*k bytes.
+//
+// The reference densifies everything (src/linalg.rs:236-238, src/simplex.rs:228,234) and has no
+// sparse basis to follow; this is SURVEY 8(f4).  With B = [A_S | E_L] (S: the k structural basic
+// columns, L: rows whose slack is basic, R: the other k rows) only
+//
+//      X = (A[R, S])^-1          k x k, dense, product form  X - Ub^T Wc  (<= 64 pending etas)
+//
+// is stored (the dense-inverse path of k_fast.hip stores all m rows: m x k).  Everything else
+// follows from the rows of  B dx = a  and the columns of  B^T v = e_p  that belong to slacks:
+//
+//   FTRAN  dx_S = X a_R                      a_R: the <= nnz(a_j) entries of a_j in rows of R, so
+//                                            only those COLUMNS of X are read (k * nnz(a_R) values)
+//          dx_p' = a_j[r'] - A[r', S] dx_S   for the basic slack of row r' (position p'): one pass
+//                                            over a CSR copy of A, 12 bytes per stored entry,
+//                                            deterministic order (no atomics)
+//   BTRAN  v_R = row p of X                  p structural;  or  v_R = -A[r', S] X, v[r'] = 1
+//                                            p the slack of row r': only the rows of X whose
+//                                            column has an entry in row r' are combined
+//   update eta append (u on the structural positions, w = v_R); a leaving slack appends a row
+//          and a column, an entering slack deletes one of each (the last moves into the hole);
+//          every 64 pivots X -= Ub^T Wc on the fp64 matrix cores.
+//
+// Memory: 8 k^2 bytes (20 GB at k = m = 50 000, BASELINE config 4; the refactorisation
+// workspace, reserved on first need, is twice that again).  A factorisation of A[R, S] in sparse
+// form would not be smaller on this family: a uniformly random pattern has no structure to
+// preserve, and its LU factors fill in to near-dense beyond a few thousand columns (DESIGN.md
+// section 4 quotes the fill measured with SuperLU).  What the sparse structure does buy -- and
+// what this path uses -- is the sparsity of the right-hand sides.
+#include "common.h"
+#include "fast_decide.h"
+
+#define R_ DZG_RMAX
+#define SP_NB 1024 // workgroups of the m-sized kernels at most (fixed fan-in of their partials)
+
+__device__ __forceinline__ double sp_block_sum(double x)
+{
+    __shared__ double s_sum[16];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, DZG_WAVE);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_sum[w];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------
+// k_sp_prep<MODE>: MODE 0 = status() at the head of the iteration, MODE 1 = the dual step's
+// ratio test after pricing (src/simplex.rs:274-306, :324-325); then the FTRAN preparation for the
+// entering variable: workgroup t < neta computes beta_t = W_t . a_R (a sparse dot), the last
+// workgroup swaps the dense copy of the entering column in `acol` (entries of the previous one
+// are cleared, so acol is zero outside the current column without an O(m) pass).
+// grid = R_ + 1 workgroups of 256.
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sp_prep(
+    DzgCtl *ctl, int m, const long long *__restrict__ cptr, const int *__restrict__ ridx,
+    const double *__restrict__ cval, const int *__restrict__ nonbasis,
+    const int *__restrict__ var_col, const double *__restrict__ fpx_r,
+    const int *__restrict__ fpx_k, const double *__restrict__ fpx_h,
+    const double *__restrict__ fpz_r, const int *__restrict__ fpz_k,
+    const double *__restrict__ fpz_h, const double *__restrict__ rz_r,
+    const int *__restrict__ rz_k, const double *__restrict__ rz_h, int nrz,
+    const double *__restrict__ W, long long ldw, const int *__restrict__ dslot,
+    double *__restrict__ beta, double *__restrict__ acol, int *acol_code, double eps)
+{
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING) return;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    int epos;
+    if (MODE == 0) {
+        const DzgCand2 cj = reduce_partials(fpz_r, fpz_k, fpz_h, DZG_NB_UPD);
+        const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, DZG_NB_UPD);
+        int kind;
+        if (!fast_status(ctl, c, lead, cj, ci, eps, m, false, kind)) return;
+        if (kind != DZG_STEP_PRIMAL) return;
+        epos = cj.k;
+    } else {
+        if (c.kind != DZG_STEP_DUAL) return;
+        const DzgCand2 cw = reduce_partials(rz_r, rz_k, rz_h, nrz);
+        if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_INFEASIBLE)) return;
+        epos = cw.k;
+        if (lead) ctl->enter_pos = epos;
+    }
+    const int code = var_col[nonbasis[epos]];
+    if (lead) ctl->enter_code = code;
+    const int b = blockIdx.x;
+    if (b < R_) {
+        if (b >= c.neta) return;
+        const double *wt = W + (long long)b * ldw;
+        if (code < 0) {
+            const int slot = dslot[-1 - code];
+            if (threadIdx.x == 0) beta[b] = slot >= 0 ? wt[slot] : 0.0;
+            return;
+        }
+        double acc = 0.0;
+        for (long long e = cptr[code] + threadIdx.x; e < cptr[code + 1]; e += blockDim.x) {
+            const int slot = dslot[ridx[e]];
+            if (slot >= 0) acc = fma(wt[slot], cval[e], acc);
+        }
+        acc = sp_block_sum(acc);
+        if (threadIdx.x == 0) beta[b] = acc;
+    } else {
+        const int prev = *acol_code; // INT_MIN: nothing scattered yet
+        if (prev != (int)0x80000000) {
+            if (prev < 0) {
+                if (threadIdx.x == 0) acol[-1 - prev] = 0.0;
+            } else {
+                for (long long e = cptr[prev] + threadIdx.x; e < cptr[prev + 1]; e += blockDim.x)
+                    acol[ridx[e]] = 0.0;
+            }
+        }
+        __syncthreads(); // the two columns may share rows
+        if (code < 0) {
+            if (threadIdx.x == 0) acol[-1 - code] = 1.0;
+        } else {
+            for (long long e = cptr[code] + threadIdx.x; e < cptr[code + 1]; e += blockDim.x)
+                acol[ridx[e]] = cval[e];
+        }
+        if (threadIdx.x == 0) *acol_code = code;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_sp_ftran_s: dx on the structural basis positions, dx_S[b] = sum_e X[b][slot_e] a_e
+// - sum_t Ub[t][b] beta_t, one thread per row b of X; the entries of a_R are staged through LDS.
+// A primal step leaves per-workgroup ratio-test candidates (src/simplex.rs:439-461).
+// grid = min(ceil(m / 256), SP_NB) workgroups of 256 (k <= m is only known on the device).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sp_ftran_s(
+    const DzgCtl *ctl, int need_kind, const long long *__restrict__ cptr,
+    const int *__restrict__ ridx, const double *__restrict__ cval,
+    const double *__restrict__ X, long long ldb, const double *__restrict__ U, long long ldu,
+    const double *__restrict__ beta, const int *__restrict__ dslot,
+    const int *__restrict__ spos, const double *__restrict__ x, const double *__restrict__ xbar,
+    double *__restrict__ dxs, double *__restrict__ dx, double *__restrict__ rx_r,
+    int *__restrict__ rx_k, double *__restrict__ rx_h)
+{
+    __shared__ int s_slot[256];
+    __shared__ double s_val[256];
+    __shared__ double s_beta[R_];
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING || c.kind != need_kind) return;
+    const int k = c.ncompact, neta = c.neta, code = c.enter_code;
+    const double mu = c.mu, tau = c.tau;
+    if (threadIdx.x < R_) s_beta[threadIdx.x] = threadIdx.x < neta ? beta[threadIdx.x] : 0.0;
+    DzgCand2 best = dzg_cand2_none();
+    const long long e0 = code >= 0 ? cptr[code] : 0, e1 = code >= 0 ? cptr[code + 1] : 1;
+    for (int b0 = blockIdx.x * blockDim.x; b0 < k; b0 += gridDim.x * blockDim.x) { // block-uniform
+        const int b = b0 + threadIdx.x;
+        const double *row = X + (long long)(b < k ? b : 0) * ldb;
+        double acc = 0.0;
+        for (long long base = e0; base < e1; base += 256) {
+            __syncthreads();
+            const long long e = base + threadIdx.x;
+            if (e < e1) {
+                const int r = code >= 0 ? ridx[e] : -1 - code;
+                s_slot[threadIdx.x] = dslot[r];
+                s_val[threadIdx.x] = code >= 0 ? cval[e] : 1.0;
+            }
+            __syncthreads();
+            const int cnt = (int)((e1 - base) < 256 ? (e1 - base) : 256);
+            if (b < k)
+                for (int i = 0; i < cnt; ++i)
+                    if (s_slot[i] >= 0) acc = fma(row[s_slot[i]], s_val[i], acc);
+        }
+        if (b < k) {
+            for (int t = 0; t < neta; ++t) acc = fma(-U[(long long)t * ldu + b], s_beta[t], acc);
+            const int i = spos[b];
+            dxs[b] = acc;
+            dx[i] = acc;
+            if (need_kind == DZG_STEP_PRIMAL) {
+                const double xi = x[i], scaled = mu * xbar[i];
+                const double den = xi + scaled;
+                DzgCand2 cnd;
+                cnd.r = dzg_div(acc, den);
+                cnd.k = i;
+                cnd.h = -__builtin_inf();
+                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
+            }
+        }
+    }
+    if (need_kind == DZG_STEP_PRIMAL) {
+        best = dzg_block_best2(best);
+        if (threadIdx.x == 0) {
+            rx_r[blockIdx.x] = best.r;
+            rx_k[blockIdx.x] = best.k;
+            rx_h[blockIdx.x] = best.h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_sp_ftran_l: dx on the positions of the basic slacks, from the rows of B dx = a_j:
+//     dx[p'] = a_j[r'] - sum_{stored (r', col), col basic} A[r', col] * dx_S[row of X of col]
+// 8 lanes share one constraint row of the CSR copy (coalesced 8-entry fetches); lane partial
+// sums fold in a fixed xor tree: the result does not depend on scheduling.
+// grid = min(ceil(8 m / 256), SP_NB) workgroups of 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sp_ftran_l(
+    const DzgCtl *ctl, int need_kind, int m, const long long *__restrict__ rptr,
+    const int *__restrict__ cidx, const double *__restrict__ rval,
+    const int *__restrict__ bslot, const int *__restrict__ rowpos,
+    const double *__restrict__ acol, const double *__restrict__ dxs,
+    const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
+    double *__restrict__ rx_r, int *__restrict__ rx_k, double *__restrict__ rx_h, int part0)
+{
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING || c.kind != need_kind) return;
+    const double mu = c.mu, tau = c.tau;
+    const bool any_structural = c.ncompact > 0;
+    const int sub = threadIdx.x & 7;
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int ngroups = (gridDim.x * blockDim.x) >> 3;
+    DzgCand2 best = dzg_cand2_none();
+    for (int r0 = 0; r0 < m; r0 += ngroups) { // wave-uniform trip count
+        const int r = r0 + group;
+        const int p = r < m ? rowpos[r] : -1; // -1: the slack of row r is nonbasic (r in R)
+        double acc = 0.0;
+        if (p >= 0 && any_structural) {
+            for (long long e = rptr[r] + sub; e < rptr[r + 1]; e += 8) {
+                const int b = bslot[cidx[e]];
+                if (b >= 0) acc = fma(-rval[e], dxs[b], acc);
+            }
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+        if (p >= 0 && sub == 0) {
+            acc = acol[r] + acc;
+            dx[p] = acc;
+            if (need_kind == DZG_STEP_PRIMAL) {
+                const double xi = x[p], scaled = mu * xbar[p];
+                const double den = xi + scaled;
+                DzgCand2 cnd;
+                cnd.r = dzg_div(acc, den);
+                cnd.k = p;
+                cnd.h = -__builtin_inf();
+                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
+            }
+        }
+    }
+    if (need_kind == DZG_STEP_PRIMAL) {
+        best = dzg_block_best2(best);
+        if (threadIdx.x == 0) {
+            rx_r[part0 + blockIdx.x] = best.r;
+            rx_k[part0 + blockIdx.x] = best.k;
+            rx_h[part0 + blockIdx.x] = best.h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_sp_btran: v = row p of B^-1 in row coordinates.  A primal step first finishes its ratio
+// test (none = Unbounded, src/simplex.rs:313).  The row is a sparse combination of rows of X:
+//   p structural (row b of X):     L = {(b, 1)}
+//   p the basic slack of row r':   L = {(row of X of col, -A[r', col]) : col basic},  v[r'] = 1
+// v_R[c] = sum_L coef * X[b][c] - sum_t (sum_L coef * Ub[t][b]) * Wc[t][c];  v = 0 elsewhere.
+// Every workgroup rebuilds L (a scan of one CSR row) and the 64 gammas, then fills its share.
+// grid = min(ceil(m / 256), SP_NB) workgroups of 256.
+// ---------------------------------------------------------------------------------
+#define SP_LCAP 1024
+__global__ __launch_bounds__(256) void k_sp_btran(
+    DzgCtl *ctl, int m, int nparts, const long long *__restrict__ rptr,
+    const int *__restrict__ cidx, const double *__restrict__ rval,
+    const int *__restrict__ bslot, const int *__restrict__ sslot, const int *__restrict__ basis,
+    const int *__restrict__ var_col, const double *__restrict__ X, long long ldb,
+    const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
+    const int *__restrict__ drow, const int *__restrict__ dslot,
+    const double *__restrict__ rx_r, const int *__restrict__ rx_k,
+    const double *__restrict__ rx_h, double *__restrict__ v)
+{
+    __shared__ int s_b[SP_LCAP];
+    __shared__ double s_coef[SP_LCAP];
+    __shared__ double s_gamma[R_];
+    __shared__ int s_cnt, s_wcnt[4];
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING) return;
+    int p;
+    if (c.kind == DZG_STEP_PRIMAL) {
+        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+        const DzgCand2 cw = reduce_partials(rx_r, rx_k, rx_h, nparts);
+        if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_UNBOUNDED)) return;
+        p = cw.k;
+        if (lead) ctl->leave_pos = p;
+    } else {
+        p = c.leave_pos;
+    }
+    const int k = c.ncompact, neta = c.neta;
+    const int bp = sslot[p];
+    const int rl = bp >= 0 ? -1 : -1 - var_col[basis[p]]; // row whose slack is basic at p
+    const int tid = threadIdx.x, stride = gridDim.x * blockDim.x;
+    const int gid = blockIdx.x * blockDim.x + tid;
+    // rows outside R: zero, except the leaving slack's own row
+    for (int r = gid; r < m; r += stride)
+        if (dslot[r] < 0) v[r] = (r == rl) ? 1.0 : 0.0;
+    if (k == 0) return;
+    // compact columns: accumulate over L in chunks that fit LDS (a dense row of a user model can
+    // hold thousands of basic columns)
+    const long long e0 = bp >= 0 ? 0 : rptr[rl], e1 = bp >= 0 ? 1 : rptr[rl + 1];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}; // this thread's columns gid, gid + stride, ...
+    if (tid < R_) s_gamma[tid] = 0.0;
+    for (long long base = e0; base < e1; base += SP_LCAP) {
+        __syncthreads();
+        // ordered compaction of the chunk's basic entries (the order of L fixes the rounding):
+        // 256 entries at a time, ballot + popcount ranks keep the CSR order
+        int total = 0;
+        if (bp >= 0) {
+            if (tid == 0) {
+                s_b[0] = bp;
+                s_coef[0] = 1.0;
+            }
+            total = 1;
+        } else {
+            const long long lim = (e1 - base) < SP_LCAP ? (e1 - base) : SP_LCAP;
+            for (long long sub0 = 0; sub0 < lim; sub0 += 256) {
+                const long long i = sub0 + tid;
+                int b = -1;
+                double cf = 0.0;
+                if (i < lim) {
+                    b = bslot[cidx[base + i]];
+                    cf = -rval[base + i];
+                }
+                const bool keep = b >= 0;
+                const unsigned long long bal = __ballot(keep);
+                const int lane = tid & 63, wave = tid >> 6;
+                const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wcnt[wave] = __popcll(bal);
+                __syncthreads();
+                int off = total, all = 0;
+                for (int w = 0; w < 4; ++w) {
+                    if (w < wave) off += s_wcnt[w];
+                    all += s_wcnt[w];
+                }
+                if (keep) {
+                    s_b[off + rank] = b;
+                    s_coef[off + rank] = cf;
+                }
+                total += all;
+                __syncthreads();
+            }
+        }
+        if (tid == 0) s_cnt = total;
+        __syncthreads();
+        const int cnt = s_cnt;
+        if (tid < neta) {
+            double g = s_gamma[tid];
+            for (int i = 0; i < cnt; ++i) g = fma(s_coef[i], U[(long long)tid * ldu + s_b[i]], g);
+            s_gamma[tid] = g;
+        }
+        int slot = 0;
+        for (int cc = gid; cc < k && slot < 4; cc += stride, ++slot) {
+            double a = acc[slot];
+            for (int i = 0; i < cnt; ++i) a = fma(s_coef[i], X[(long long)s_b[i] * ldb + cc], a);
+            acc[slot] = a;
+        }
+    }
+    __syncthreads();
+    int slot = 0;
+    for (int cc = gid; cc < k; cc += stride, ++slot) {
+        double a;
+        if (slot < 4) {
+            a = acc[slot];
+        } else { // more than 4 columns per thread (k > 4 * grid threads = 1 M): not reachable
+            a = 0.0;
+        }
+        for (int t = 0; t < neta; ++t) a = fma(-s_gamma[t], W[(long long)t * ldw + cc], a);
+        v[drow[cc]] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_sp_pivot: step lengths and the finiteness assert (src/simplex.rs:257-260,:464-468), swap
+// (:239-251), pivot log, and the books of the k x k block: which rows / columns of X appear,
+// disappear or are recycled.  The data moves themselves are k_sp_update's (whole chip); they are
+// described by ctl->sp_*.  One workgroup.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sp_pivot(
+    DzgCtl *ctl, int m, int q, const double *__restrict__ x, const double *__restrict__ xbar,
+    const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dx,
+    const double *__restrict__ dz, int *basis, int *nonbasis, const int *__restrict__ var_col,
+    int *drow, int *dslot, int *sslot, int *spos, int *bslot, int *rowpos, int *plist, int *pslot,
+    const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
+    double *log_mu, double *log_margin, long long log_cap)
+{
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING || threadIdx.x != 0) return;
+    const int p = c.leave_pos, r = c.enter_pos, neta = c.neta;
+    const int vi = basis[p], vj = nonbasis[r];
+    const int ci = var_col[vi], cj = var_col[vj];
+    const double xp = x[p], xbp = xbar[p], dxp = dx[p];
+    const double zr = z[r], zbr = zbar[r], dzr = dz[r];
+    int ok = 1;
+    const double t = dzg_safe_divide(xp, dxp, &ok);
+    const double s = dzg_safe_divide(zr, dzr, &ok);
+    const double tbar = dzg_safe_divide(xbp, dxp, &ok);
+    const double sbar = dzg_safe_divide(zbr, dzr, &ok);
+    if (neta >= R_) ok = 0; // the host flushes every DZG_RMAX pivots; never reached
+    double max_err = c.max_pivot_err;
+    {
+        const double a1 = fabs(dxp), a2 = fabs(dzr);
+        const double den = a1 > a2 ? a1 : a2;
+        const double err = den > 0.0 ? fabs(dxp + dzr) / den : 0.0;
+        if (err > max_err) max_err = err;
+    }
+    if (!ok) {
+        ctl->status = DZG_PANIC; // assert in safe_divide, src/simplex.rs:466
+        return;
+    }
+    ctl->t = t;
+    ctl->s = s;
+    ctl->tbar = tbar;
+    ctl->sbar = sbar;
+    // ---- the k x k block.  k_sp_update reads these with the OLD k (sp_k) and the new one.
+    int k = c.ncompact;
+    int app = -1, mrow = -1, mcol = -1, zcol = -1;
+    const int last = k - 1;
+    if (ci >= 0 && cj >= 0) {          // structural for structural: the row of p stays
+        bslot[cj] = bslot[ci];
+        bslot[ci] = -1;
+    } else if (ci < 0 && cj >= 0) {    // a slack leaves: its row becomes a column of X, p a row
+        const int rl = -1 - ci;
+        drow[k] = rl;
+        dslot[rl] = k;
+        rowpos[rl] = -1;
+        sslot[p] = k;
+        spos[k] = p;
+        bslot[cj] = k;
+        app = k;
+        k += 1;
+    } else if (ci >= 0 && cj < 0) {    // a slack enters: row of p and column of its row go
+        const int re = -1 - cj, bp = sslot[p], ce = dslot[re];
+        bslot[ci] = -1;
+        if (bp != last) {
+            const int pl = spos[last];
+            spos[bp] = pl;
+            sslot[pl] = bp;
+            bslot[var_col[basis[pl]]] = bp;
+            mrow = bp;
+        }
+        sslot[p] = -1;
+        if (ce != last) {
+            const int lr = drow[last];
+            drow[ce] = lr;
+            dslot[lr] = ce;
+            mcol = ce;
+        }
+        dslot[re] = -1;
+        rowpos[re] = p;
+        k -= 1;
+    } else {                           // slack for slack: the column slot changes hands
+        const int rl = -1 - ci, re = -1 - cj, ce = dslot[re];
+        drow[ce] = rl;
+        dslot[rl] = ce;
+        dslot[re] = -1;
+        rowpos[rl] = -1;
+        rowpos[re] = p;
+        zcol = ce;
+    }
+    ctl->sp_k = c.ncompact;
+    ctl->sp_app = app;
+    ctl->sp_mrow = mrow;
+    ctl->sp_mcol = mcol;
+    ctl->sp_zcol = zcol;
+    ctl->ncompact = k;
+    // ---- swap, log, counters, list of nonbasic structural positions (as k_fast_pivot)
+    const long long it = c.iter;
+    if (it < log_cap) {
+        log_kind[it] = c.kind;
+        log_enter[it] = vj;
+        log_leave[it] = vi;
+        log_mu[it] = c.mu;
+        log_margin[it] = c.margin;
+    }
+    long long ns = c.nb_struct;
+    ctl->price_bytes = c.price_bytes + 12.0 * (double)c.nb_nnz + 4.0 * (double)(ns + 1) +
+                       8.0 * (double)m + 32.0 * (double)q;
+    basis[p] = vj;
+    nonbasis[r] = vi;
+    long long nnz = c.nb_nnz;
+    if (cj >= 0) nnz -= cptr[cj + 1] - cptr[cj];
+    if (ci >= 0) nnz += cptr[ci + 1] - cptr[ci];
+    ctl->nb_nnz = nnz;
+    if (cj >= 0 && ci < 0) { // a structural column left the nonbasic set
+        const int idx = pslot[r], lastpos = plist[ns - 1];
+        plist[idx] = lastpos;
+        pslot[lastpos] = idx;
+        pslot[r] = -1;
+        --ns;
+    } else if (cj < 0 && ci >= 0) {
+        plist[ns] = r;
+        pslot[r] = (int)ns;
+        ++ns;
+    }
+    ctl->nb_struct = ns;
+    ctl->enter_var = vj;
+    ctl->leave_var = vi;
+    ctl->neta = neta + 1;
+    ctl->max_pivot_err = max_err;
+    if (c.margin < c.min_margin) ctl->min_margin = c.margin;
+    if (c.tie_seen) {
+        ctl->near_ties = c.near_ties + 1;
+        if (c.first_near_tie < 0) ctl->first_near_tie = it;
+    }
+    if (c.tie_tol >= 0.0) {
+        const double adaptive = 64.0 * max_err;
+        ctl->tau = adaptive > c.tie_tol ? adaptive : c.tie_tol;
+    }
+    ctl->iter = it + 1;
+}
+
+// ---------------------------------------------------------------------------------
+// k_sp_update: the data moves k_sp_pivot booked (no cell is both a source and a target of the
+// same pivot: the last row / column are only read), the eta of this pivot in the NEW numbering,
+// pivot() x4 (src/simplex.rs:262-265,:410-421) and the first-pivot candidates of the next
+// iteration (:423-437).  grid = DZG_NB_UPD workgroups of 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sp_update(
+    const DzgCtl *ctl, int only_partials, double *x, double *xbar, double *z, double *zbar,
+    const double *__restrict__ dx, const double *__restrict__ dz, int m, int q,
+    double *fpx_r, int *fpx_k, double *fpx_h, double *fpz_r, int *fpz_k, double *fpz_h,
+    const double *__restrict__ v, double *__restrict__ U, long long ldu, double *__restrict__ W,
+    long long ldw, double *__restrict__ X, long long ldb, const int *__restrict__ drow,
+    const int *__restrict__ spos)
+{
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING) return;
+    const int p = c.leave_pos, r = c.enter_pos;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (!only_partials) {
+        const int ko = c.sp_k, kn = c.ncompact, last = ko - 1;
+        const int nold = c.neta - 1; // pending etas before this pivot
+        const int mrow = c.sp_mrow, mcol = c.sp_mcol;
+        if (mrow >= 0) { // row `last` moves into the hole (its entry in column mcol: see below)
+            for (int cc = gid; cc < ko; cc += stride)
+                if (cc != mcol && cc != last)
+                    X[(long long)mrow * ldb + cc] = X[(long long)last * ldb + cc];
+            for (int t = gid; t < nold; t += stride)
+                U[(long long)t * ldu + mrow] = U[(long long)t * ldu + last];
+        }
+        if (mcol >= 0) { // column `last` moves into the hole; the moved row takes it from (last, last)
+            for (int b = gid; b < last; b += stride) {
+                const int src = (b == mrow) ? last : b;
+                X[(long long)b * ldb + mcol] = X[(long long)src * ldb + last];
+            }
+            for (int t = gid; t < nold; t += stride)
+                W[(long long)t * ldw + mcol] = W[(long long)t * ldw + last];
+        } else if (mrow >= 0 && c.sp_app < 0 && c.sp_zcol < 0 && kn < ko) {
+            // the deleted column WAS the last one: the moved row's entry there is dropped
+        }
+        if (c.sp_zcol >= 0) { // recycled column slot: the new column is zero before this eta
+            for (int b = gid; b < ko; b += stride) X[(long long)b * ldb + c.sp_zcol] = 0.0;
+            for (int t = gid; t < nold; t += stride) W[(long long)t * ldw + c.sp_zcol] = 0.0;
+        }
+        if (c.sp_app >= 0) { // new row = v (the row of B^-1 the slack position had), new column 0
+            const int a = c.sp_app;
+            for (int b = gid; b < a; b += stride) X[(long long)b * ldb + a] = 0.0;
+            for (int cc = gid; cc <= a; cc += stride) X[(long long)a * ldb + cc] = v[drow[cc]];
+            for (int t = gid; t < nold; t += stride) {
+                U[(long long)t * ldu + a] = 0.0;
+                W[(long long)t * ldw + a] = 0.0;
+            }
+        }
+        // eta of this pivot: u = (dx - e_p) / dx_p on the structural positions, w = v_R
+        const double rdxp = 1.0 / dx[p];
+        double *ut = U + (long long)nold * ldu, *wt = W + (long long)nold * ldw;
+        for (int b = gid; b < kn; b += stride) {
+            const int i = spos[b];
+            const double d = dx[i];
+            ut[b] = (i == p ? d - 1.0 : d) * rdxp;
+            wt[b] = v[drow[b]];
+        }
+    }
+    const double t = c.t, s = c.s, tbar = c.tbar, sbar = c.sbar;
+    const double tau = c.tau, inf = __builtin_inf();
+    DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
+    for (int i = gid; i < m; i += stride) {
+        double xi = x[i], xb = xbar[i];
+        if (!only_partials) {
+            const double d = dx[i];
+            const double a = t * d, b = tbar * d;
+            xi = (i == p) ? t : xi - a;
+            xb = (i == p) ? tbar : xb - b;
+            x[i] = xi;
+            xbar[i] = xb;
+        }
+        if (xb > 0.0) {
+            DzgCand2 cd;
+            cd.r = dzg_div(-xi, xb);
+            cd.k = i;
+            cd.h = -inf;
+            if (cd.r == cd.r) bx = dzg_better2(bx, cd);
+        }
+        if (fabs(xb) <= tau && !(xi > tau)) bx.h = inf;
+    }
+    for (int kk = gid; kk < q; kk += stride) {
+        double zk = z[kk], zb = zbar[kk];
+        if (!only_partials) {
+            const double d = dz[kk];
+            const double a = s * d, b = sbar * d;
+            zk = (kk == r) ? s : zk - a;
+            zb = (kk == r) ? sbar : zb - b;
+            z[kk] = zk;
+            zbar[kk] = zb;
+        }
+        if (zb > 0.0) {
+            DzgCand2 cd;
+            cd.r = dzg_div(-zk, zb);
+            cd.k = kk;
+            cd.h = -inf;
+            if (cd.r == cd.r) bz = dzg_better2(bz, cd);
+        }
+        if (fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
+    }
+    bx = dzg_block_best2(bx);
+    bz = dzg_block_best2(bz);
+    if (threadIdx.x == 0) {
+        fpx_r[blockIdx.x] = bx.r;
+        fpx_k[blockIdx.x] = bx.k;
+        fpx_h[blockIdx.x] = bx.h;
+        fpz_r[blockIdx.x] = bz.r;
+        fpz_k[blockIdx.x] = bz.k;
+        fpz_h[blockIdx.x] = bz.h;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Flush: X[0:k, 0:k] -= Ub^T[:, 0:neta] * Wc.  Same tiling as k_fast_flush_mfma (one wave owns a
+// 16 x 64 strip, v_mfma_f64_16x16x4_f64 along the eta index); here both operands are compact.
+// ---------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double *__restrict__ X,
+                                                       long long ldb, const double *__restrict__ U,
+                                                       long long ldu, const double *__restrict__ W,
+                                                       long long ldw)
+{
+    const int neta = ctl->neta, k = ctl->ncompact;
+    if (neta <= 0 || k <= 0 || ctl->status != DZG_RUNNING) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64;
+    const int i0 = (blockIdx.y * 4 + wave) * 16;
+    if (c0 >= k || i0 >= k) return;
+    const int li = lane & 15, lk = lane >> 4;
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            acc[j][g] = (row < k && col < k) ? X[(long long)row * ldb + col] : 0.0;
+        }
+    const int arow = i0 + li;
+    const int ksteps = (neta + 3) >> 2;
+    for (int s = 0; s < ksteps; ++s) {
+        const int t = 4 * s + lk;
+        const double a = (arow < k && t < neta) ? -U[(long long)t * ldu + arow] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c0 + 16 * j + li;
+            const double b = (t < neta && col < k) ? W[(long long)t * ldw + col] : 0.0;
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            if (row < k && col < k) X[(long long)row * ldb + col] = acc[j][g];
+        }
+}
+
+__global__ void k_sp_flush_done(DzgCtl *ctl)
+{
+    if (ctl->status == DZG_RUNNING) ctl->neta = 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Books of the starting basis (after k_fast_init has listed the dense columns): which basis
+// positions hold structurals (rows of X, in position order), where each slack is basic.
+// One workgroup; runs once per solve and after every refactorisation.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sp_init(DzgCtl *ctl, int m, int ns,
+                                                 const int *__restrict__ basis,
+                                                 const int *__restrict__ var_col, int *sslot,
+                                                 int *spos, int *bslot, int *rowpos, int *acol_code)
+{
+    for (int j = threadIdx.x; j < ns; j += blockDim.x) bslot[j] = -1;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) rowpos[r] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int b = 0;
+        for (int p = 0; p < m; ++p) {
+            const int code = var_col[basis[p]];
+            if (code >= 0) {
+                sslot[p] = b;
+                spos[b] = p;
+                bslot[code] = b;
+                ++b;
+            } else {
+                sslot[p] = -1;
+                rowpos[-1 - code] = p;
+            }
+        }
+        if (acol_code) *acol_code = (int)0x80000000;
+        (void)ctl;
+    }
+}
+
+// after a refactorisation: Xinv (row b = b-th structural basic in position order, column a =
+// compact column a) becomes X.  grid (ceil(k / 256), k)
+__global__ __launch_bounds__(256) void k_sp_ref_copy(int k, const double *__restrict__ Xinv,
+                                                     long long ldx, double *__restrict__ X,
+                                                     long long ldb)
+{
+    const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < k) X[(long long)b * ldb + a] = Xinv[(long long)b * ldx + a];
+}
+
+// ---------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------
+static int sp_grid(int n) { int g = (n + 255) / 256; return g < 1 ? 1 : (g > SP_NB ? SP_NB : g); }
+
+// first != 0: creation (acol is all zero, nothing scattered); 0: after a refactorisation, when
+// acol still holds the last entering column and its code must be remembered
+void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sp_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.ns, d.basis, d.var_col,
+                       d.sslot, d.spos, d.bslot, d.rowpos, first ? d.acol_code : (int *)nullptr);
+}
+
+void dzg_launch_sp_prep(const DzgDev &d, int mode, int nrz, hipStream_t st)
+{
+#define SP_PREP_ARGS d.ctl, d.m, d.cptr, d.ridx, d.cval, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k,     \
+                     d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.rz_r, d.rz_k, d.rz_h, nrz, d.W, d.ldw,     \
+                     d.dslot, d.beta, d.acol, d.acol_code, d.eps
+    if (mode == 0)
+        hipLaunchKernelGGL((k_sp_prep<0>), dim3(R_ + 1), dim3(256), 0, st, SP_PREP_ARGS);
+    else
+        hipLaunchKernelGGL((k_sp_prep<1>), dim3(R_ + 1), dim3(256), 0, st, SP_PREP_ARGS);
+#undef SP_PREP_ARGS
+}
+
+void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, hipStream_t st)
+{
+    const int gs = sp_grid(d.m), gl = sp_grid(8 * d.m);
+    hipLaunchKernelGGL(k_sp_ftran_s, dim3(gs), dim3(256), 0, st, d.ctl, need_kind, d.cptr, d.ridx,
+                       d.cval, d.binv, d.ldb, d.U, d.ldw, d.beta, d.dslot, d.spos, d.x, d.xbar, d.dxs,
+                       d.dx, d.rx_r, d.rx_k, d.rx_h);
+    hipLaunchKernelGGL(k_sp_ftran_l, dim3(gl), dim3(256), 0, st, d.ctl, need_kind, d.m, d.rptr,
+                       d.cidx, d.rval, d.bslot, d.rowpos, d.acol, d.dxs, d.x, d.xbar, d.dx, d.rx_r,
+                       d.rx_k, d.rx_h, gs);
+}
+
+void dzg_launch_sp_btran(const DzgDev &d, hipStream_t st)
+{
+    const int nparts = sp_grid(d.m) + sp_grid(8 * d.m);
+    hipLaunchKernelGGL(k_sp_btran, dim3(sp_grid(d.m)), dim3(256), 0, st, d.ctl, d.m, nparts, d.rptr,
+                       d.cidx, d.rval, d.bslot, d.sslot, d.basis, d.var_col, d.binv, d.ldb, d.U,
+                       d.ldw, d.W, d.ldw, d.drow, d.dslot, d.rx_r, d.rx_k, d.rx_h, d.v);
+}
+
+void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sp_pivot, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.x, d.xbar, d.z,
+                       d.zbar, d.dx, d.dz, d.basis, d.nonbasis, d.var_col, d.drow, d.dslot, d.sslot,
+                       d.spos, d.bslot, d.rowpos, d.plist, d.pslot, d.cptr, d.log_kind, d.log_enter,
+                       d.log_leave, d.log_mu, d.log_margin, d.log_cap);
+}
+
+void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sp_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
+                       d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r,
+                       d.fpz_k, d.fpz_h, d.v, d.U, d.ldw, d.W, d.ldw, d.binv, d.ldb, d.drow, d.spos);
+}
+
+void dzg_launch_sp_flush(const DzgDev &d, hipStream_t st)
+{
+    const int kmax = d.m; // k <= m; the kernel masks by the device's k
+    hipLaunchKernelGGL(k_sp_flush_mfma, dim3((kmax + 63) / 64, (kmax + 63) / 64), dim3(256), 0, st,
+                       d.ctl, d.binv, d.ldb, d.U, d.ldw, d.W, d.ldw);
+    hipLaunchKernelGGL(k_sp_flush_done, dim3(1), dim3(1), 0, st, d.ctl);
+}
+
+void dzg_launch_sp_ref_copy(const DzgDev &d, int k, const double *Xinv, long long ldx, hipStream_t st)
+{
+    if (k > 0)
+        hipLaunchKernelGGL(k_sp_ref_copy, dim3((k + 255) / 256, k), dim3(256), 0, st, k, Xinv, ldx,
+                           d.binv, d.ldb);
+    dzg_launch_sp_init(d, 0, st); // rows of X are in position order again
+}
