@@ -328,6 +328,9 @@ struct DzgDev {
     int *spos;             // [m]  basis position of row b of X
     int *bslot;            // [ns] row of X of structural column j when it is basic, else -1
     int *rowpos;           // [m]  basis position of the slack of constraint row r, -1: nonbasic
+    int *bcnt;             // [m]  entries of constraint row r in BASIC structural columns ...
+    int *bcol;             // [nnz] ... their columns, in row r's CSR slice (rptr[r] + i) ...
+    double *bval;          // [nnz] ... and values
     double *dxs;           // [m]  dx on the structural positions, by row of X
     int *acol_code;        // column code currently scattered in acol (INT_MIN: none)
     // strict numerics

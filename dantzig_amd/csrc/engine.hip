@@ -332,6 +332,9 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                 HIP_OK(hipMemcpy(drv, rv.data(), sizeof(double) * rv.size(), hipMemcpyHostToDevice));
             }
             d.rptr = drp; d.cidx = dci; d.rval = drv;
+            TRY(dev_alloc(s, &d.bcnt, (size_t)(m ? m : 1)));
+            TRY(dev_alloc(s, &d.bcol, ci.size() + 1));
+            TRY(dev_alloc(s, &d.bval, rv.size() + 1));
         }
     }
     // --- constraint matrix: column-major, zero-padded to lda rows (16-B aligned columns)
@@ -526,9 +529,16 @@ static int price_kernel_for(const dzg_solver *s)
     // AUTO: FAST numerics streams with the register-accumulator kernel, whose sums depend only
     // on m (bit-identical dz on one GPU and on any column sharding); the reference-order kernel
     // (bit-identical to neg_t_dot) belongs to STRICT, whose v is the reference's v.
-    if (s->d.csc) return DZG_PRICE_CSC_KERNEL;
+    if (s->d.csc) // CSC: the tree-order kernel unless the options insist on the reference's order
+        return s->opts.price_kernel == DZG_PRICE_SEQ ? DZG_PRICE_SEQ : DZG_PRICE_CSC_KERNEL;
     if (s->opts.price_kernel != DZG_PRICE_AUTO) return s->opts.price_kernel;
     return DZG_PRICE_TREE;
+}
+
+// per-workgroup ratio partials the pricing pass leaves (every CSC kernel uses the same grid)
+static int price_partials_for(const dzg_solver *s, int pk)
+{
+    return dzg_price_partials(s->d.csc ? DZG_PRICE_CSC_KERNEL : pk);
 }
 
 static void enqueue_fast_iteration(dzg_solver *s, int slot)
@@ -550,7 +560,7 @@ static void enqueue_fast_iteration(dzg_solver *s, int slot)
     dzg_launch_price_fast(d, pk, st); // dz (+ dual ratio partials)
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_RATIO);
-    dzg_launch_fast_select_prep(d, 1, dzg_price_partials(pk), nullptr, st); // dual: ratio + prep
+    dzg_launch_fast_select_prep(d, 1, price_partials_for(s, pk), nullptr, st); // dual: ratio + prep
     dzg_launch_fast_gemv(d, DZG_STEP_DUAL, nullptr, st);                    // dual step: dx last
     pf.end(DZG_K_RATIO);
     pf.begin(DZG_K_UPDATE);
@@ -584,7 +594,7 @@ static void enqueue_sparse_iteration(dzg_solver *s, int slot)
     dzg_launch_sp_btran(d, st);
     pf.end(DZG_K_BTRAN);
     pf.begin(DZG_K_PRICE);
-    dzg_launch_price_fast(d, DZG_PRICE_CSC_KERNEL, st);
+    dzg_launch_price_fast(d, price_kernel_for(s), st);
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_RATIO);
     dzg_launch_sp_prep(d, 1, dzg_price_partials(DZG_PRICE_CSC_KERNEL), st);
@@ -909,7 +919,7 @@ extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *s
     if (prof) hipEventRecord(s->ev[ev0], st);
     dzg_launch_price_fast(d, pk, st);                      // owned columns only
     if (prof) hipEventRecord(s->ev[ev0 + 1], st);
-    dzg_launch_shard_propose(d, 1, dzg_price_partials(pk), send_dev, st);
+    dzg_launch_shard_propose(d, 1, price_partials_for(s, pk), send_dev, st);
     return 0;
 }
 

@@ -54,19 +54,26 @@ int dzg_price_partials(int kernel)
 }
 
 static void launch_csc(const DzgDev &d, const int *plist, const double *z, const double *zbar,
-                       double *rz_r, int *rz_k, double *rz_h, hipStream_t st)
+                       double *rz_r, int *rz_k, double *rz_h, bool seq_order, hipStream_t st)
 {
     if (d.q <= 0) return;
-    hipLaunchKernelGGL(k_price_csc, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl, d.cptr,
-                       d.ridx, d.cval, d.q, plist, d.nonbasis, d.var_col, d.v, d.dz, z, zbar, rz_r,
-                       rz_k, rz_h, d.col0);
+    // FAST (ratio test fused: z != nullptr) sums in tree order unless the caller insists on the
+    // reference's order; STRICT always takes the reference's order
+    if (z && !seq_order)
+        hipLaunchKernelGGL(k_price_csc_tree, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl,
+                           d.cptr, d.ridx, d.cval, d.q, plist, d.nonbasis, d.var_col, d.v, d.dz, z,
+                           zbar, rz_r, rz_k, rz_h, d.col0);
+    else
+        hipLaunchKernelGGL(k_price_csc, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl, d.cptr,
+                           d.ridx, d.cval, d.q, plist, d.nonbasis, d.var_col, d.v, d.dz, z, zbar,
+                           rz_r, rz_k, rz_h, d.col0);
 }
 
 // STRICT numerics: every nonbasic position, no fused ratio test
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
 {
     if (d.csc) {
-        launch_csc(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+        launch_csc(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, st);
         return;
     }
     launch(kernel, d.q, d.ctl, d.A, d.lda, d.m, d.q, nullptr, d.nonbasis, d.var_col, d.v, d.dz, nullptr,
@@ -77,7 +84,7 @@ void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
 {
     if (d.csc) {
-        launch_csc(d, d.plist, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, st);
+        launch_csc(d, d.plist, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, kernel == DZG_PRICE_SEQ, st);
         return;
     }
     launch(kernel, d.col1 - d.col0, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nonbasis, d.var_col, d.v, d.dz, d.z,

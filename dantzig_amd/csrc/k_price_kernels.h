@@ -524,6 +524,62 @@ __global__ __launch_bounds__(256) void k_price_csc(
     price_publish(best, rz_r, rz_k, rz_h);
 }
 
+// ---------------------------------------------------------------------------------
+// k_price_csc_tree: the FAST-numerics twin of k_price_csc.  Same 8 lanes per column and the same
+// coalesced 8-entry fetches, but every lane keeps its own partial sum (entries sub, sub + 8, ...)
+// and the eight partials fold in an xor tree: no 50-long chain of dependent shuffles per column,
+// the pass is bound by the gathers of v (L2-resident) and the 12 bytes per stored entry.  The
+// order of a column's sum depends on nothing but the column (deterministic, shard-independent);
+// it is not the reference's order, which only STRICT numerics needs (its v is the reference's v).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_price_csc_tree(
+    const DzgCtl *ctl, const long long *__restrict__ cptr, const int *__restrict__ ridx,
+    const double *__restrict__ cval, int q, const int *__restrict__ plist,
+    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const double *__restrict__ v, double *__restrict__ dz, const double *__restrict__ z,
+    const double *__restrict__ zbar, double *__restrict__ rz_r, int *__restrict__ rz_k,
+    double *__restrict__ rz_h, int col0)
+{
+    if (ctl && ctl->status != DZG_RUNNING) return;
+    const double mu = ctl ? ctl->mu : 0.0, tau = ctl ? ctl->tau : 0.0;
+    DzgCand2 best = dzg_cand2_none();
+    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, tau, z, zbar);
+    const int count = plist ? (int)ctl->nb_struct : q;
+    const int sub = threadIdx.x & 7;
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int ngroups = (gridDim.x * blockDim.x) >> 3;
+    for (int idx0 = 0; idx0 < count; idx0 += ngroups) { // wave-uniform trip count
+        const int idx = idx0 + group;
+        int pos = -1, code = -1;
+        long long e0 = 0, e1 = 0;
+        if (idx < count) {
+            pos = plist ? plist[idx] : idx;
+            code = price_code(nonbasis, var_col, pos);
+            if (code >= 0) {
+                e0 = cptr[code - col0];
+                e1 = cptr[code - col0 + 1];
+            }
+        }
+        double a0 = 0.0, a1 = 0.0; // two independent chains per lane
+        long long e = e0 + sub;
+        for (; e + 8 < e1; e += 16) {
+            const int r0 = ridx[e], r1 = ridx[e + 8];
+            const double c0 = cval[e], c1 = cval[e + 8];
+            a0 = fma(c0, v[r0], a0);
+            a1 = fma(c1, v[r1], a1);
+        }
+        if (e < e1) a0 = fma(cval[e], v[ridx[e]], a0);
+        double acc = a0 + a1;
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+        if (code >= 0 && sub == 0) {
+            dz[pos] = -acc;
+            if (z) price_candidate(best, -acc, pos, mu, tau, z, zbar);
+        }
+    }
+    price_publish(best, rz_r, rz_k, rz_h);
+}
+
 #define DZG_PRICE_CSC_BLOCKS 2048
 #define DZG_PRICE_SEQ_BLOCKS 256   // x 4 waves: one workgroup per CU
 #define DZG_PRICE_WAVE_BLOCKS 2048 // x 4 waves

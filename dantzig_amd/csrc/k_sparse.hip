@@ -34,6 +34,7 @@
 
 #define R_ DZG_RMAX
 #define SP_NB 1024 // workgroups of the m-sized kernels at most (fixed fan-in of their partials)
+#define SP_NB_UPD 256 // workgroups of k_sp_update = first-pivot partials per side
 
 __device__ __forceinline__ double sp_block_sum(double x)
 {
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) void k_sp_prep(
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     int epos;
     if (MODE == 0) {
-        const DzgCand2 cj = reduce_partials(fpz_r, fpz_k, fpz_h, DZG_NB_UPD);
-        const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, DZG_NB_UPD);
+        const DzgCand2 cj = reduce_partials(fpz_r, fpz_k, fpz_h, SP_NB_UPD);
+        const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, SP_NB_UPD);
         int kind;
         if (!fast_status(ctl, c, lead, cj, ci, eps, m, false, kind)) return;
         if (kind != DZG_STEP_PRIMAL) return;
@@ -197,14 +198,16 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
 
 // ---------------------------------------------------------------------------------
 // k_sp_ftran_l: dx on the positions of the basic slacks, from the rows of B dx = a_j:
-//     dx[p'] = a_j[r'] - sum_{stored (r', col), col basic} A[r', col] * dx_S[row of X of col]
-// 8 lanes share one constraint row of the CSR copy (coalesced 8-entry fetches); lane partial
-// sums fold in a fixed xor tree: the result does not depend on scheduling.
-// grid = min(ceil(8 m / 256), SP_NB) workgroups of 256.
+//     dx[p'] = a_j[r'] - sum_{col basic, A[r', col] stored} A[r', col] * dx_S[row of X of col]
+// Each constraint row keeps the list of its entries in BASIC structural columns (bcnt / bcol /
+// bval, in the row's slice of the CSR-shaped buffers; k_sp_pivot appends the entering column's
+// entries and removes the leaving one's), so the pass touches k * nnz-per-column entries, not
+// nnz(A).  One thread per row walks its list in list order: deterministic, no atomics.
+// grid = min(ceil(m / 256), SP_NB) workgroups of 256.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sp_ftran_l(
     const DzgCtl *ctl, int need_kind, int m, const long long *__restrict__ rptr,
-    const int *__restrict__ cidx, const double *__restrict__ rval,
+    const int *__restrict__ bcnt, const int *__restrict__ bcol, const double *__restrict__ bval,
     const int *__restrict__ bslot, const int *__restrict__ rowpos,
     const double *__restrict__ acol, const double *__restrict__ dxs,
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
@@ -213,36 +216,24 @@ __global__ __launch_bounds__(256) void k_sp_ftran_l(
     const DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING || c.kind != need_kind) return;
     const double mu = c.mu, tau = c.tau;
-    const bool any_structural = c.ncompact > 0;
-    const int sub = threadIdx.x & 7;
-    const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const int ngroups = (gridDim.x * blockDim.x) >> 3;
     DzgCand2 best = dzg_cand2_none();
-    for (int r0 = 0; r0 < m; r0 += ngroups) { // wave-uniform trip count
-        const int r = r0 + group;
-        const int p = r < m ? rowpos[r] : -1; // -1: the slack of row r is nonbasic (r in R)
-        double acc = 0.0;
-        if (p >= 0 && any_structural) {
-            for (long long e = rptr[r] + sub; e < rptr[r + 1]; e += 8) {
-                const int b = bslot[cidx[e]];
-                if (b >= 0) acc = fma(-rval[e], dxs[b], acc);
-            }
-        }
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
-        if (p >= 0 && sub == 0) {
-            acc = acol[r] + acc;
-            dx[p] = acc;
-            if (need_kind == DZG_STEP_PRIMAL) {
-                const double xi = x[p], scaled = mu * xbar[p];
-                const double den = xi + scaled;
-                DzgCand2 cnd;
-                cnd.r = dzg_div(acc, den);
-                cnd.k = p;
-                cnd.h = -__builtin_inf();
-                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
-                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
-            }
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < m; r += gridDim.x * blockDim.x) {
+        const int p = rowpos[r]; // -1: the slack of row r is nonbasic (r in R)
+        if (p < 0) continue;
+        double acc = acol[r];
+        const long long e0 = rptr[r];
+        const int n = bcnt[r];
+        for (int i = 0; i < n; ++i) acc = fma(-bval[e0 + i], dxs[bslot[bcol[e0 + i]]], acc);
+        dx[p] = acc;
+        if (need_kind == DZG_STEP_PRIMAL) {
+            const double xi = x[p], scaled = mu * xbar[p];
+            const double den = xi + scaled;
+            DzgCand2 cnd;
+            cnd.r = dzg_div(acc, den);
+            cnd.k = p;
+            cnd.h = -__builtin_inf();
+            if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+            if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
         }
     }
     if (need_kind == DZG_STEP_PRIMAL) {
@@ -261,13 +252,14 @@ __global__ __launch_bounds__(256) void k_sp_ftran_l(
 //   p structural (row b of X):     L = {(b, 1)}
 //   p the basic slack of row r':   L = {(row of X of col, -A[r', col]) : col basic},  v[r'] = 1
 // v_R[c] = sum_L coef * X[b][c] - sum_t (sum_L coef * Ub[t][b]) * Wc[t][c];  v = 0 elsewhere.
-// Every workgroup rebuilds L (a scan of one CSR row) and the 64 gammas, then fills its share.
+// Every workgroup reads L (the row's list of basic entries) and forms the 64 gammas, then fills
+// its share of v.
 // grid = min(ceil(m / 256), SP_NB) workgroups of 256.
 // ---------------------------------------------------------------------------------
 #define SP_LCAP 1024
 __global__ __launch_bounds__(256) void k_sp_btran(
     DzgCtl *ctl, int m, int nparts, const long long *__restrict__ rptr,
-    const int *__restrict__ cidx, const double *__restrict__ rval,
+    const int *__restrict__ bcnt, const int *__restrict__ bcol, const double *__restrict__ bval,
     const int *__restrict__ bslot, const int *__restrict__ sslot, const int *__restrict__ basis,
     const int *__restrict__ var_col, const double *__restrict__ X, long long ldb,
     const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
@@ -278,7 +270,7 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     __shared__ int s_b[SP_LCAP];
     __shared__ double s_coef[SP_LCAP];
     __shared__ double s_gamma[R_];
-    __shared__ int s_cnt, s_wcnt[4];
+    __shared__ int s_cnt;
     const DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     int p;
@@ -302,7 +294,7 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     if (k == 0) return;
     // compact columns: accumulate over L in chunks that fit LDS (a dense row of a user model can
     // hold thousands of basic columns)
-    const long long e0 = bp >= 0 ? 0 : rptr[rl], e1 = bp >= 0 ? 1 : rptr[rl + 1];
+    const long long e0 = bp >= 0 ? 0 : rptr[rl], e1 = bp >= 0 ? 1 : e0 + bcnt[rl];
     double acc[4] = {0.0, 0.0, 0.0, 0.0}; // this thread's columns gid, gid + stride, ...
     if (tid < R_) s_gamma[tid] = 0.0;
     for (long long base = e0; base < e1; base += SP_LCAP) {
@@ -316,34 +308,13 @@ __global__ __launch_bounds__(256) void k_sp_btran(
                 s_coef[0] = 1.0;
             }
             total = 1;
-        } else {
+        } else { // the row's basic entries, in list order
             const long long lim = (e1 - base) < SP_LCAP ? (e1 - base) : SP_LCAP;
-            for (long long sub0 = 0; sub0 < lim; sub0 += 256) {
-                const long long i = sub0 + tid;
-                int b = -1;
-                double cf = 0.0;
-                if (i < lim) {
-                    b = bslot[cidx[base + i]];
-                    cf = -rval[base + i];
-                }
-                const bool keep = b >= 0;
-                const unsigned long long bal = __ballot(keep);
-                const int lane = tid & 63, wave = tid >> 6;
-                const int rank = __popcll(bal & ((1ull << lane) - 1ull));
-                if (lane == 0) s_wcnt[wave] = __popcll(bal);
-                __syncthreads();
-                int off = total, all = 0;
-                for (int w = 0; w < 4; ++w) {
-                    if (w < wave) off += s_wcnt[w];
-                    all += s_wcnt[w];
-                }
-                if (keep) {
-                    s_b[off + rank] = b;
-                    s_coef[off + rank] = cf;
-                }
-                total += all;
-                __syncthreads();
+            for (long long i = tid; i < lim; i += blockDim.x) {
+                s_b[i] = bslot[bcol[base + i]];
+                s_coef[i] = -bval[base + i];
             }
+            total = (int)lim;
         }
         if (tid == 0) s_cnt = total;
         __syncthreads();
@@ -374,25 +345,17 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     }
 }
 
-// ---------------------------------------------------------------------------------
-// k_sp_pivot: step lengths and the finiteness assert (src/simplex.rs:257-260,:464-468), swap
-// (:239-251), pivot log, and the books of the k x k block: which rows / columns of X appear,
-// disappear or are recycled.  The data moves themselves are k_sp_update's (whole chip); they are
-// described by ctl->sp_*.  One workgroup.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sp_pivot(
-    DzgCtl *ctl, int m, int q, const double *__restrict__ x, const double *__restrict__ xbar,
+// The single-lane part of k_sp_pivot: step lengths, the books of the k x k block, swap, log,
+// counters.  Returns 0 when a step length is not finite (DZG_PANIC).
+__device__ __forceinline__ int sp_pivot_books(
+    DzgCtl *ctl, const DzgCtl &c, int m, int q, int p, int r, int neta, int vi, int vj, int ci,
+    int cj, const double *__restrict__ x, const double *__restrict__ xbar,
     const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dx,
     const double *__restrict__ dz, int *basis, int *nonbasis, const int *__restrict__ var_col,
     int *drow, int *dslot, int *sslot, int *spos, int *bslot, int *rowpos, int *plist, int *pslot,
     const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
     double *log_mu, double *log_margin, long long log_cap)
 {
-    const DzgCtl c = *ctl;
-    if (c.status != DZG_RUNNING || threadIdx.x != 0) return;
-    const int p = c.leave_pos, r = c.enter_pos, neta = c.neta;
-    const int vi = basis[p], vj = nonbasis[r];
-    const int ci = var_col[vi], cj = var_col[vj];
     const double xp = x[p], xbp = xbar[p], dxp = dx[p];
     const double zr = z[r], zbr = zbar[r], dzr = dz[r];
     int ok = 1;
@@ -410,7 +373,7 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
     }
     if (!ok) {
         ctl->status = DZG_PANIC; // assert in safe_divide, src/simplex.rs:466
-        return;
+        return 0;
     }
     ctl->t = t;
     ctl->s = s;
@@ -512,13 +475,74 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
         ctl->tau = adaptive > c.tie_tol ? adaptive : c.tie_tol;
     }
     ctl->iter = it + 1;
+    return 1;
 }
+
+// ---------------------------------------------------------------------------------
+// k_sp_pivot: step lengths and the finiteness assert (src/simplex.rs:257-260,:464-468), swap
+// (:239-251), pivot log, and the books of the k x k block: which rows / columns of X appear,
+// disappear or are recycled.  The data moves themselves are k_sp_update's (whole chip); they are
+// described by ctl->sp_*.  One workgroup.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sp_pivot(
+    DzgCtl *ctl, int m, int q, const double *__restrict__ x, const double *__restrict__ xbar,
+    const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dx,
+    const double *__restrict__ dz, int *basis, int *nonbasis, const int *__restrict__ var_col,
+    int *drow, int *dslot, int *sslot, int *spos, int *bslot, int *rowpos, int *plist, int *pslot,
+    const long long *__restrict__ cptr, const int *__restrict__ ridx,
+    const double *__restrict__ cval, const long long *__restrict__ rptr, int *bcnt, int *bcol,
+    double *bval, int *log_kind, int *log_enter, int *log_leave, double *log_mu,
+    double *log_margin, long long log_cap)
+{
+    __shared__ int s_ok, s_ci, s_cj;
+    const DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING) return;
+    if (threadIdx.x == 0) { // one lane reads the pivot's variables BEFORE it swaps them
+        const int p = c.leave_pos, r = c.enter_pos;
+        const int vi = basis[p], vj = nonbasis[r];
+        s_ci = var_col[vi];
+        s_cj = var_col[vj];
+        s_ok = sp_pivot_books(ctl, c, m, q, p, r, c.neta, vi, vj, s_ci, s_cj, x, xbar, z, zbar, dx, dz,
+                              basis, nonbasis, var_col, drow, dslot, sslot, spos, bslot, rowpos,
+                              plist, pslot, cptr, log_kind, log_enter, log_leave, log_mu,
+                              log_margin, log_cap);
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const int ci = s_ci, cj = s_cj;
+    // per-row lists of entries in basic columns: drop the leaving column's, append the entering
+    // one's.  A column has at most one entry per row: no two threads touch the same list within
+    // a phase; the barrier orders removal before insertion for rows both columns touch.
+    if (ci >= 0)
+        for (long long e = cptr[ci] + threadIdx.x; e < cptr[ci + 1]; e += blockDim.x) {
+            const int row = ridx[e];
+            const long long e0 = rptr[row];
+            const int n = bcnt[row];
+            for (int i = 0; i < n; ++i)
+                if (bcol[e0 + i] == ci) {
+                    bcol[e0 + i] = bcol[e0 + n - 1];
+                    bval[e0 + i] = bval[e0 + n - 1];
+                    break;
+                }
+            bcnt[row] = n - 1;
+        }
+    __syncthreads();
+    if (cj >= 0)
+        for (long long e = cptr[cj] + threadIdx.x; e < cptr[cj + 1]; e += blockDim.x) {
+            const int row = ridx[e];
+            const int n = bcnt[row];
+            bcol[rptr[row] + n] = cj;
+            bval[rptr[row] + n] = cval[e];
+            bcnt[row] = n + 1;
+        }
+}
+
 
 // ---------------------------------------------------------------------------------
 // k_sp_update: the data moves k_sp_pivot booked (no cell is both a source and a target of the
 // same pivot: the last row / column are only read), the eta of this pivot in the NEW numbering,
 // pivot() x4 (src/simplex.rs:262-265,:410-421) and the first-pivot candidates of the next
-// iteration (:423-437).  grid = DZG_NB_UPD workgroups of 256.
+// iteration (:423-437).  grid = SP_NB_UPD workgroups of 256.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sp_update(
     const DzgCtl *ctl, int only_partials, double *x, double *xbar, double *z, double *zbar,
@@ -713,6 +737,27 @@ __global__ __launch_bounds__(256) void k_sp_init(DzgCtl *ctl, int m, int ns,
     }
 }
 
+// basic-entry lists from scratch (creation with a non-slack basis, after a refactorisation):
+// row r keeps, in CSR order, its entries whose column is basic.  grid over rows.
+__global__ __launch_bounds__(256) void k_sp_lists(int m, const long long *__restrict__ rptr,
+                                                  const int *__restrict__ cidx,
+                                                  const double *__restrict__ rval,
+                                                  const int *__restrict__ bslot, int *bcnt,
+                                                  int *bcol, double *bval)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < m; r += gridDim.x * blockDim.x) {
+        const long long e0 = rptr[r];
+        int n = 0;
+        for (long long e = e0; e < rptr[r + 1]; ++e)
+            if (bslot[cidx[e]] >= 0) {
+                bcol[e0 + n] = cidx[e];
+                bval[e0 + n] = rval[e];
+                ++n;
+            }
+        bcnt[r] = n;
+    }
+}
+
 // after a refactorisation: Xinv (row b = b-th structural basic in position order, column a =
 // compact column a) becomes X.  grid (ceil(k / 256), k)
 __global__ __launch_bounds__(256) void k_sp_ref_copy(int k, const double *__restrict__ Xinv,
@@ -734,6 +779,8 @@ void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st)
 {
     hipLaunchKernelGGL(k_sp_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.ns, d.basis, d.var_col,
                        d.sslot, d.spos, d.bslot, d.rowpos, first ? d.acol_code : (int *)nullptr);
+    hipLaunchKernelGGL(k_sp_lists, dim3(sp_grid(d.m)), dim3(256), 0, st, d.m, d.rptr, d.cidx, d.rval,
+                       d.bslot, d.bcnt, d.bcol, d.bval);
 }
 
 void dzg_launch_sp_prep(const DzgDev &d, int mode, int nrz, hipStream_t st)
@@ -750,20 +797,20 @@ void dzg_launch_sp_prep(const DzgDev &d, int mode, int nrz, hipStream_t st)
 
 void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, hipStream_t st)
 {
-    const int gs = sp_grid(d.m), gl = sp_grid(8 * d.m);
+    const int gs = sp_grid(d.m), gl = sp_grid(d.m);
     hipLaunchKernelGGL(k_sp_ftran_s, dim3(gs), dim3(256), 0, st, d.ctl, need_kind, d.cptr, d.ridx,
                        d.cval, d.binv, d.ldb, d.U, d.ldw, d.beta, d.dslot, d.spos, d.x, d.xbar, d.dxs,
                        d.dx, d.rx_r, d.rx_k, d.rx_h);
     hipLaunchKernelGGL(k_sp_ftran_l, dim3(gl), dim3(256), 0, st, d.ctl, need_kind, d.m, d.rptr,
-                       d.cidx, d.rval, d.bslot, d.rowpos, d.acol, d.dxs, d.x, d.xbar, d.dx, d.rx_r,
-                       d.rx_k, d.rx_h, gs);
+                       d.bcnt, d.bcol, d.bval, d.bslot, d.rowpos, d.acol, d.dxs, d.x, d.xbar, d.dx,
+                       d.rx_r, d.rx_k, d.rx_h, gs);
 }
 
 void dzg_launch_sp_btran(const DzgDev &d, hipStream_t st)
 {
-    const int nparts = sp_grid(d.m) + sp_grid(8 * d.m);
+    const int nparts = 2 * sp_grid(d.m);
     hipLaunchKernelGGL(k_sp_btran, dim3(sp_grid(d.m)), dim3(256), 0, st, d.ctl, d.m, nparts, d.rptr,
-                       d.cidx, d.rval, d.bslot, d.sslot, d.basis, d.var_col, d.binv, d.ldb, d.U,
+                       d.bcnt, d.bcol, d.bval, d.bslot, d.sslot, d.basis, d.var_col, d.binv, d.ldb, d.U,
                        d.ldw, d.W, d.ldw, d.drow, d.dslot, d.rx_r, d.rx_k, d.rx_h, d.v);
 }
 
@@ -771,13 +818,14 @@ void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_sp_pivot, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.x, d.xbar, d.z,
                        d.zbar, d.dx, d.dz, d.basis, d.nonbasis, d.var_col, d.drow, d.dslot, d.sslot,
-                       d.spos, d.bslot, d.rowpos, d.plist, d.pslot, d.cptr, d.log_kind, d.log_enter,
-                       d.log_leave, d.log_mu, d.log_margin, d.log_cap);
+                       d.spos, d.bslot, d.rowpos, d.plist, d.pslot, d.cptr, d.ridx, d.cval, d.rptr, d.bcnt,
+                       d.bcol, d.bval, d.log_kind, d.log_enter, d.log_leave, d.log_mu, d.log_margin,
+                       d.log_cap);
 }
 
 void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sp_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
+    hipLaunchKernelGGL(k_sp_update, dim3(SP_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
                        d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r,
                        d.fpz_k, d.fpz_h, d.v, d.U, d.ldw, d.W, d.ldw, d.binv, d.ldb, d.drow, d.spos);
 }
