@@ -229,7 +229,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
              "tree": core.PRICE_TREE}[price_name]
     numerics = core.FAST if numerics_name == "fast" else core.STRICT
-    kernel = "k_price_csc" if sparse_per_col > 0 else (
+    kernel = ("k_price_csc_tree" if numerics_name == "fast" and price_name != "seq"
+              else "k_price_csc") if sparse_per_col > 0 else (
         "k_price_seq2" if numerics_name == "strict" else PRICE_KERNELS[price_name])
     t_up = time.perf_counter()
     solver = core.Solver(lp, numerics=numerics, price_kernel=price,

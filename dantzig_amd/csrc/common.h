@@ -369,6 +369,7 @@ int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st);
 int dzg_price_partials(int kernel);
+int dzg_price_partials_dev(const DzgDev &d, int kernel);
 #define DZG_PRICE_CSC_KERNEL 100 // internal id: the CSC pricing kernel
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st);

@@ -538,7 +538,7 @@ static int price_kernel_for(const dzg_solver *s)
 // per-workgroup ratio partials the pricing pass leaves (every CSC kernel uses the same grid)
 static int price_partials_for(const dzg_solver *s, int pk)
 {
-    return dzg_price_partials(s->d.csc ? DZG_PRICE_CSC_KERNEL : pk);
+    return dzg_price_partials_dev(s->d, pk);
 }
 
 static void enqueue_fast_iteration(dzg_solver *s, int slot)
@@ -597,7 +597,7 @@ static void enqueue_sparse_iteration(dzg_solver *s, int slot)
     dzg_launch_price_fast(d, price_kernel_for(s), st);
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_RATIO);
-    dzg_launch_sp_prep(d, 1, dzg_price_partials(DZG_PRICE_CSC_KERNEL), st);
+    dzg_launch_sp_prep(d, 1, price_partials_for(s, price_kernel_for(s)), st);
     dzg_launch_sp_ftran(d, DZG_STEP_DUAL, st);
     pf.end(DZG_K_RATIO);
     pf.begin(DZG_K_UPDATE);

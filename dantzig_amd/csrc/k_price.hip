@@ -48,9 +48,16 @@ static void launch(int kernel, int ncols, const DzgCtl *ctl, const double *A, lo
 // number of per-workgroup ratio partials the chosen kernel leaves in rz_r / rz_k
 int dzg_price_partials(int kernel)
 {
-    if (kernel == DZG_PRICE_CSC_KERNEL) return DZG_PRICE_CSC_BLOCKS;
+    if (kernel == DZG_PRICE_CSC_KERNEL) return DZG_PRICE_CSC_BLOCKS; // an upper bound: see below
     if (resolve(kernel) == DZG_PRICE_TREE) return DZG_PRICE_TREE_BLOCKS;
     return resolve(kernel) == DZG_PRICE_WAVE ? DZG_PRICE_WAVE_BLOCKS : DZG_PRICE_SEQ_BLOCKS;
+}
+
+// partial count of the pass dzg_launch_price_fast(d, kernel) will run
+int dzg_price_partials_dev(const DzgDev &d, int kernel)
+{
+    if (!d.csc) return dzg_price_partials(kernel);
+    return DZG_PRICE_CSC_BLOCKS;
 }
 
 static void launch_csc(const DzgDev &d, const int *plist, const double *z, const double *zbar,

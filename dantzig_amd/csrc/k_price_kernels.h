@@ -528,7 +528,12 @@ __global__ __launch_bounds__(256) void k_price_csc(
 // k_price_csc_tree: the FAST-numerics twin of k_price_csc.  Same 8 lanes per column and the same
 // coalesced 8-entry fetches, but every lane keeps its own partial sum (entries sub, sub + 8, ...)
 // and the eight partials fold in an xor tree: no 50-long chain of dependent shuffles per column,
-// the pass is bound by the gathers of v (L2-resident) and the 12 bytes per stored entry.  The
+// the pass is bound by the gathers of v (L2-resident: 8 bytes used of every 128-byte line that
+// travels to a CU -- 718 MB of L2 sectors per launch for 63 MB of matrix, PMC counters in
+// profiles/r02_pmc_price_csc_summary.txt) and the 12 bytes per stored entry.  (A variant that staged v through LDS in 16 384-row
+// blocks, one 1024-thread workgroup per CU, measured SLOWER -- 42.3 us against 34.1 us per launch
+// at config 4, profiles/r02_config4_kernel_stats_lds_pricing_variant.csv: four barrier-separated
+// phases with 16 waves per CU hide the latency of the entry stream worse than 32 free waves.)  The
 // order of a column's sum depends on nothing but the column (deterministic, shard-independent);
 // it is not the reference's order, which only STRICT numerics needs (its v is the reference's v).
 // ---------------------------------------------------------------------------------
