@@ -21,8 +21,10 @@ STRICT, FAST, AUTO = 0, 1, 2
 PRICE_AUTO, PRICE_SEQ, PRICE_WAVE, PRICE_TREE = 0, 1, 2, 3
 STEP_PRIMAL, STEP_DUAL = 0, 1
 NEAR_TIE_COUNT, NEAR_TIE_STOP = 0, 1
-K_STATUS, K_FTRAN, K_RATIO, K_BTRAN, K_PRICE, K_UPDATE, K_BASIS_UPDATE, K_LU, K_COUNT = range(9)
-KERNEL_CLASSES = ["status", "ftran", "ratio", "btran", "price", "update", "basis_update", "lu"]
+(K_STATUS, K_FTRAN, K_RATIO, K_BTRAN, K_PRICE, K_UPDATE, K_BASIS_UPDATE, K_LU, K_XCHG1, K_XCHG2,
+ K_COUNT) = range(11)
+KERNEL_CLASSES = ["status", "ftran", "ratio", "btran", "price", "update", "basis_update", "lu",
+                  "exchange1", "exchange2"]
 
 EXPORTS = [
     "dzg_abi_version", "dzg_status_str", "dzg_last_error", "dzg_device_count",
@@ -34,6 +36,7 @@ EXPORTS = [
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
     "dzg_gen_dense_lp_block", "dzg_solver_set_profile", "dzg_kernel_neg_t_dot_csc",
+    "dzg_shard_comm_size",
 ]
 
 
@@ -145,6 +148,7 @@ def lib() -> C.CDLL:
         _lib.dzg_comm_unique_id.argtypes = [C.c_void_p]
         _lib.dzg_shard_comm_init.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dzg_shard_run.argtypes = [C.c_void_p, C.c_int64]
+        _lib.dzg_shard_comm_size.argtypes = [C.c_void_p]
         _lib.dzg_shard_run_lockstep.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
         _lib.dzg_solver_stream.restype = C.c_void_p
         _lib.dzg_solver_stream.argtypes = [C.c_void_p]

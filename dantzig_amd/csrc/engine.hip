@@ -178,6 +178,7 @@ struct Rccl {
     int (*CommInitRank)(void **, int, NcclUniqueId, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -198,6 +199,7 @@ Rccl &rccl()
     r.CommInitRank = (int (*)(void **, int, NcclUniqueId, int))dlsym(r.handle, "ncclCommInitRank");
     r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.handle, "ncclAllGather");
     r.CommDestroy = (int (*)(void *))dlsym(r.handle, "ncclCommDestroy");
+    r.CommCount = (int (*)(void *, int *))dlsym(r.handle, "ncclCommCount");
     r.GetErrorString = (const char *(*)(int))dlsym(r.handle, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
     return r;
@@ -618,8 +620,8 @@ static void collect_profile(dzg_solver *s, int slots_real)
     for (int slot = 0; slot < slots_real; ++slot)
         for (int cls = 0; cls < DZG_K_COUNT; ++cls) {
             if (!(s->opts.profile & (1 << cls))) continue;
-            if (((s->d.csc && !s->d.spb) || s->d.world > 1 || s->comm) && cls != DZG_K_PRICE)
-                continue; // the phase path only stamps pricing
+            if (s->d.csc && !s->d.spb && s->d.world == 1 && !s->comm && cls != DZG_K_PRICE)
+                continue; // the single-GPU record path of a CSC solver only stamps pricing
             float ms = 0.f;
             size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
             if (hipEventElapsedTime(&ms, s->ev[base], s->ev[base + 1]) == hipSuccess) {
@@ -897,10 +899,19 @@ extern "C" int dzg_solver_poll(dzg_solver *s, int32_t *status, int64_t *iteratio
 // ---- column sharding: three enqueue-only phases per iteration (dantzig_amd.h) ---------
 extern "C" int64_t dzg_shard_record_doubles(const dzg_solver *s) { return s ? s->d.xstride : 0; }
 
+// event stamps of the phase path: slot = s->prof_slot (< 0: none)
+static void phase_stamp(dzg_solver *s, int cls, int end)
+{
+    if (s->prof_slot >= 0 && (s->opts.profile & (1 << cls)))
+        hipEventRecord(s->ev[((size_t)s->prof_slot * DZG_K_COUNT + cls) * 2 + end], s->st);
+}
+
 extern "C" int dzg_shard_phase1(dzg_solver *s, double *send_dev)
 {
     if (!s || !send_dev || s->numerics != DZG_NUMERICS_FAST) return fail(DZG_E_ARG, "phase1");
+    phase_stamp(s, DZG_K_STATUS, 0);
     dzg_launch_shard_propose(s->d, 0, 0, send_dev, s->st);
+    phase_stamp(s, DZG_K_STATUS, 1);
     return 0;
 }
 
@@ -911,15 +922,17 @@ extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *s
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     const int pk = price_kernel_for(s);
+    phase_stamp(s, DZG_K_FTRAN, 0);
     dzg_launch_fast_select_prep(d, 4, 0, recv_dev, st);    // merge + status() + primal FTRAN prep
     dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, recv_dev, st);
     dzg_launch_fast_btran(d, st);
-    const bool prof = s->prof_slot >= 0 && (s->opts.profile & (1 << DZG_K_PRICE));
-    const size_t ev0 = prof ? ((size_t)s->prof_slot * DZG_K_COUNT + DZG_K_PRICE) * 2 : 0;
-    if (prof) hipEventRecord(s->ev[ev0], st);
+    phase_stamp(s, DZG_K_FTRAN, 1);
+    phase_stamp(s, DZG_K_PRICE, 0);
     dzg_launch_price_fast(d, pk, st);                      // owned columns only
-    if (prof) hipEventRecord(s->ev[ev0 + 1], st);
+    phase_stamp(s, DZG_K_PRICE, 1);
+    phase_stamp(s, DZG_K_RATIO, 0);
     dzg_launch_shard_propose(d, 1, price_partials_for(s, pk), send_dev, st);
+    phase_stamp(s, DZG_K_RATIO, 1);
     return 0;
 }
 
@@ -928,6 +941,7 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
     if (!s || !recv_dev || s->numerics != DZG_NUMERICS_FAST) return fail(DZG_E_ARG, "phase3");
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
+    phase_stamp(s, DZG_K_UPDATE, 0);
     dzg_launch_fast_select_prep(d, 5, 0, recv_dev, st);    // merge + (dual) FTRAN prep
     dzg_launch_fast_gemv(d, DZG_STEP_DUAL, recv_dev, st);
     dzg_launch_fast_pivot(d, st);
@@ -936,6 +950,7 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
         dzg_launch_fast_flush(d, st);
         s->since_flush = 0;
     }
+    phase_stamp(s, DZG_K_UPDATE, 1);
     return 0;
 }
 
@@ -985,6 +1000,15 @@ extern "C" int dzg_shard_comm_init(dzg_solver *s, const void *unique_id_128)
     return shard_buffers(s);
 }
 
+extern "C" int dzg_shard_comm_size(dzg_solver *s)
+{
+    if (!s || !s->comm) return fail(DZG_E_ARG, "dzg_shard_comm_init first");
+    Rccl &r = rccl();
+    int n = 0;
+    if (!r.CommCount || r.CommCount(s->comm, &n) != 0) return fail(DZG_E_DEVICE, "ncclCommCount");
+    return n;
+}
+
 extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
 {
     if (!s || !s->comm) return fail(DZG_E_ARG, "dzg_shard_comm_init first");
@@ -1006,11 +1030,15 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
+            phase_stamp(s, DZG_K_XCHG1, 0);
             if (r.AllGather(s->xsend, s->xrecv1, n, kNcclFloat64, s->comm, s->st) != 0)
                 return fail(DZG_E_DEVICE, "ncclAllGather (exchange 1)");
+            phase_stamp(s, DZG_K_XCHG1, 1);
             TRY(dzg_shard_phase2(s, s->xrecv1, s->xsend));
+            phase_stamp(s, DZG_K_XCHG2, 0);
             if (r.AllGather(s->xsend, s->xrecv2, n, kNcclFloat64, s->comm, s->st) != 0)
                 return fail(DZG_E_DEVICE, "ncclAllGather (exchange 2)");
+            phase_stamp(s, DZG_K_XCHG2, 1);
             TRY(dzg_shard_phase3(s, s->xrecv2));
         }
         s->prof_slot = -1;

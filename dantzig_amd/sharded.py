@@ -57,6 +57,11 @@ class ShardedSolver(core.Solver):
         _ffi.check(rc, "dzg_shard_run")
         return core.STATUS_NAMES[rc]
 
+    def comm_size(self) -> int:
+        rc = _ffi.lib().dzg_shard_comm_size(self._h)
+        _ffi.check(rc, "dzg_shard_comm_size")
+        return int(rc)
+
     def poll(self) -> tuple[str, int]:
         st, it = C.c_int32(0), C.c_int64(0)
         _ffi.check(_ffi.lib().dzg_solver_poll(self._h, C.byref(st), C.byref(it)), "poll")
@@ -96,9 +101,11 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
     a, b, c = core.gen_dense_lp_block(seed, rows, cols, begin, end)
     lp = core.CoreLP.from_inequality_block(a, b, c, begin, end)
     t_gen = time.perf_counter() - t_gen
-    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE}[price_name]
+    price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
+             "tree": core.PRICE_TREE}[price_name]
+    # poll interval 50 divides the default warm-up and step counts: no partial batches
     solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price,
-                           profile=1 << _ffi.K_PRICE)
+                           profile=1 << _ffi.K_PRICE, poll_interval=50)
     try:
         del a, lp
         uid = torch.zeros(128, dtype=torch.uint8)
@@ -106,6 +113,7 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
             uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(uid, src=0)
         solver.comm_init(uid.numpy().tobytes())
+        nranks = solver.comm_size()
 
         status = "iter_limit"
         if warmup > 0:
@@ -124,6 +132,28 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
         pb = torch.tensor([res.price_bytes], dtype=torch.float64)
         dist.all_reduce(pb, op=dist.ReduceOp.SUM)
         record_bytes = 8 * solver.record_doubles
+        # per-phase split, OUTSIDE the timed region (event stamps cost time): 200 more pivots with
+        # every phase and both all-gathers bracketed by HIP events on this rank's stream
+        phases = None
+        if status == "iter_limit":
+            solver.set_profile((1 << _ffi.K_COUNT) - 1)
+            if solver.run(200) in ("iter_limit", "optimal"):
+                rp = solver.result(log=False)
+                n = max(rp.iterations - res.iterations, 1)
+                labels = {"status": "propose first-pivot record", "exchange1": "all-gather 1",
+                          "ftran": "merge + status + FTRAN + BTRAN", "price": "pricing (own columns)",
+                          "ratio": "propose second record", "exchange2": "all-gather 2",
+                          "update": "merge + (dual) FTRAN + pivot + update + flush"}
+                mine = torch.tensor([1e3 * (rp.kernel_ms[k] - res.kernel_ms[k]) / n for k in labels],
+                                    dtype=torch.float64)
+                worst = mine.clone()
+                dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+                phases = {"pivots": n, "us_per_iteration_rank0": dict(zip(labels.values(),
+                                                                         [round(x, 2) for x in mine.tolist()])),
+                          "us_per_iteration_max_over_ranks": dict(zip(labels.values(),
+                                                                      [round(x, 2) for x in worst.tolist()])),
+                          "note": "an all-gather's time runs from the moment this rank's stream "
+                                  "reaches it: waiting for a slower rank is counted there"}
     finally:
         solver.close()
     dt = float(elapsed.item())
@@ -145,6 +175,7 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
             "status_after_timed_region": status, "requested_steps": steps,
             "exchanges_per_iteration": 2, "record_bytes": record_bytes,
             "collective": "ncclAllGather (RCCL) of one record per rank",
+            "nranks_ncclCommCount": nranks,
             "lp_generation_s": round(t_gen, 3),
             "max_pivot_error": res.max_pivot_error,
         },
@@ -154,6 +185,7 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
             "traffic": None, "avg_launch_us": 1e3 * d_ms / max(d_launch, 1),
         },
         "cpu_baseline": None,
+        "phases": phases,
         "pricing_bytes_all_ranks": float(pb.item()),
     }
 
@@ -187,7 +219,7 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
         sec = _measure_sharded(dist, torch, 32768, 65536, 1005, "auto", 300, 50, rank, world,
                                local_rank)
         out["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step",
-                                                "config", "roofline")}
+                                                "config", "roofline", "phases")}
     dist.destroy_process_group()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -161,7 +161,13 @@ typedef struct {
 /* Kernel classes for the time/byte counters. */
 enum {
     DZG_K_STATUS = 0, DZG_K_FTRAN, DZG_K_RATIO, DZG_K_BTRAN, DZG_K_PRICE, DZG_K_UPDATE,
-    DZG_K_BASIS_UPDATE, DZG_K_LU, DZG_K_COUNT
+    DZG_K_BASIS_UPDATE, DZG_K_LU,
+    /* column-sharded loop (dzg_shard_run): the two all-gathers, from the moment the stream
+     * reaches them to their completion (so waiting for a slower rank is counted here).  In that
+     * loop STATUS = proposing the first-pivot candidate, FTRAN = the basis kernels before
+     * pricing, RATIO = proposing the second record, UPDATE = everything after exchange 2. */
+    DZG_K_XCHG1, DZG_K_XCHG2,
+    DZG_K_COUNT
 };
 
 typedef struct {
@@ -364,6 +370,8 @@ int dzg_shard_phase3(dzg_solver *s, const double *recv_dev);
 int dzg_comm_unique_id(void *unique_id_128);
 int dzg_shard_comm_init(dzg_solver *s, const void *unique_id_128);
 int dzg_shard_run(dzg_solver *s, int64_t max_new_iters);
+/* Ranks of the communicator as RCCL counts them (ncclCommCount), or < 0. */
+int dzg_shard_comm_size(dzg_solver *s);
 /* All ranks inside one process on one device (solvers[r] created with rank r and a common
  * opts.stream = dzg_solver_stream(solvers[0])): the exchange is a device-to-device copy.
  * This is how the sharded device path is exercised on a single-GPU box. */
