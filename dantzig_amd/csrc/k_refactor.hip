@@ -7,9 +7,10 @@
 // nonbasic) only the k x k block G = A[R, S] needs factorising:
 //
 //   1. gather G (row a = dense row drow[a], column b = b-th structural basic position)
-//   2. blocked right-looking LU with partial pivoting, panel width NB = 64:
-//        panel (one workgroup: pivot search = first maximum of |.|, swap, scale, rank-1 inside
-//        the panel)  ->  row swaps outside the panel  ->  U12 = L11^-1 A12  ->
+//   2. blocked right-looking LU with partial pivoting, panel width NB = 64, the panel itself in
+//      sub-panels of 8 columns (pivot search = first maximum of |.|, swap, scale, rank-1 inside
+//      the sub-panel by one workgroup; rank-8 update of the rest of the panel by the whole chip)
+//        ->  row swaps outside the panel  ->  U12 = L11^-1 A12  ->
 //        trailing update A22 -= L21 * U12 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
 //   3. X = G^-1 by blocked forward / backward substitution on the identity, every off-diagonal
 //      block product again an MFMA GEMM
@@ -183,16 +184,27 @@ __global__ __launch_bounds__(256) void k_ref_lslot_fill(int nl, const int *__res
     if (i < nl) lslot[lrow[i]] = i;
 }
 
-// panel j0..j0+nbw: unblocked LU with partial pivoting inside the panel columns (one workgroup)
-__global__ __launch_bounds__(1024) void k_ref_panel(int k, int j0, int nbw, double *__restrict__ G,
-                                                    long long ldg, int *__restrict__ piv,
-                                                    int *__restrict__ singular)
+// The 64-column panel is factorised in sub-panels of SPW columns (a second level of blocking:
+// an elimination step then sweeps k x SPW values instead of k x 64, and the rest of the panel
+// gets one rank-SPW update per sub-panel from the whole chip instead of 64 rank-1 sweeps from one
+// workgroup).
+//   k_ref_subpanel (one workgroup): unblocked LU with partial pivoting (first maximum of |.|) of
+//     columns [c0, c0 + w); then the same workgroup applies the w row swaps to the other columns
+//     of the enclosing panel [pj0, pj0 + pnbw) and solves U12' = L11^-1 A12' for the panel
+//     columns right of the sub-panel (a w x w unit-lower triangle: one thread per column);
+//   k_ref_subupdate (whole chip): A22' -= L21 U12' on rows below the sub-panel, panel columns
+//     right of it -- one thread per row, U12' in LDS.
+#define SPW 8
+__global__ __launch_bounds__(1024) void k_ref_subpanel(int k, int pj0, int pnbw, int c0, int w,
+                                                       double *__restrict__ G, long long ldg,
+                                                       int *__restrict__ piv,
+                                                       int *__restrict__ singular)
 {
     __shared__ int s_p;
-    __shared__ double s_pivrow[NB];
+    __shared__ double s_pivrow[SPW];
     const int tid = threadIdx.x;
-    for (int jj = 0; jj < nbw; ++jj) {
-        const int col = j0 + jj;
+    for (int jj = 0; jj < w; ++jj) {
+        const int col = c0 + jj;
         DzgCand best;
         best.r = 0.0;
         best.k = -1;
@@ -210,10 +222,10 @@ __global__ __launch_bounds__(1024) void k_ref_panel(int k, int j0, int nbw, doub
         }
         __syncthreads();
         const int p = s_p;
-        // swap rows col <-> p inside the panel, keep the pivot row in LDS
-        if (tid < nbw) {
-            double *rc = G + (long long)col * ldg + j0 + tid;
-            double *rp = G + (long long)p * ldg + j0 + tid;
+        // swap rows col <-> p inside the sub-panel, keep the pivot row in LDS
+        if (tid < w) {
+            double *rc = G + (long long)col * ldg + c0 + tid;
+            double *rp = G + (long long)p * ldg + c0 + tid;
             const double a = *rc, b = *rp;
             *rc = b;
             *rp = a;
@@ -223,12 +235,179 @@ __global__ __launch_bounds__(1024) void k_ref_panel(int k, int j0, int nbw, doub
         const double pv = s_pivrow[jj];
         const double rpv = pv != 0.0 ? 1.0 / pv : 0.0;
         for (int i = col + 1 + tid; i < k; i += blockDim.x) {
-            double *row = G + (long long)i * ldg + j0;
+            double *row = G + (long long)i * ldg + c0;
             const double l = row[jj] * rpv;
             row[jj] = l;
-            for (int c = jj + 1; c < nbw; ++c) row[c] = fma(-l, s_pivrow[c], row[c]);
+            for (int c = jj + 1; c < w; ++c) row[c] = fma(-l, s_pivrow[c], row[c]);
         }
         __syncthreads();
+    }
+    // the other columns of the enclosing panel: row swaps (in pivot order), then the columns
+    // right of the sub-panel take  U12' = L11^-1 A12'
+    const int nother = pnbw - w;
+    if (tid < nother) {
+        const int off = tid < (c0 - pj0) ? tid : tid + w; // skip the sub-panel's own columns
+        double *colp = G + pj0 + off;
+        for (int jj = 0; jj < w; ++jj) {
+            const int r = c0 + jj, p = piv[r];
+            if (p != r) {
+                const double a = colp[(long long)r * ldg], b = colp[(long long)p * ldg];
+                colp[(long long)r * ldg] = b;
+                colp[(long long)p * ldg] = a;
+            }
+        }
+        if (pj0 + off >= c0 + w) { // right of the sub-panel
+            double y[SPW];
+            for (int i = 0; i < w; ++i) y[i] = colp[(long long)(c0 + i) * ldg];
+            for (int i = 1; i < w; ++i) {
+                double acc = y[i];
+                for (int j = 0; j < i; ++j)
+                    acc = fma(-G[(long long)(c0 + i) * ldg + c0 + j], y[j], acc);
+                y[i] = acc;
+            }
+            for (int i = 0; i < w; ++i) colp[(long long)(c0 + i) * ldg] = y[i];
+        }
+    }
+}
+
+// The same sub-panel step with the active rows held in REGISTERS: thread t owns rows
+// c0 + t, c0 + t + 1024, ... (SPR of them at most, i.e. k - c0 <= 1024 * SPR), loads their SPW
+// values once, runs the w elimination steps on registers -- per step one block-wide max-loc, one
+// exchange of the two swapped rows through LDS -- and writes them back once.  The strided
+// column reads of the global-memory version (one cache line per row and step) disappear.
+template <int SPR, int W> // SPR x W values per thread: 4 x 8 and 8 x 4 stay in registers
+__global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int pnbw, int c0, int w,
+                                                           double *__restrict__ G, long long ldg,
+                                                           int *__restrict__ piv,
+                                                           int *__restrict__ singular)
+{
+    __shared__ double s_rowc[W], s_rowp[W];
+    __shared__ int s_p;
+    const int tid = threadIdx.x;
+    double a[SPR][W];
+#pragma unroll
+    for (int r = 0; r < SPR; ++r) {
+        const int i = c0 + tid + 1024 * r;
+#pragma unroll
+        for (int c = 0; c < W; ++c) a[r][c] = (i < k && c < w) ? G[(long long)i * ldg + c0 + c] : 0.0;
+    }
+#pragma unroll
+    for (int jj = 0; jj < W; ++jj) {
+        if (jj >= w) break;
+        const int col = c0 + jj;
+        DzgCand best;
+        best.r = 0.0;
+        best.k = -1;
+#pragma unroll
+        for (int r = 0; r < SPR; ++r) {
+            const int i = c0 + tid + 1024 * r;
+            if (i >= col && i < k) {
+                DzgCand c;
+                c.r = fabs(a[r][jj]);
+                c.k = i;
+                if (c.r == c.r) best = dzg_better(best, c);
+            }
+        }
+        best = dzg_block_best(best);
+        const int p = best.k >= 0 ? best.k : col;
+        if (tid == 0) {
+            piv[col] = p;
+            if (!(best.r > 0.0)) *singular = 1;
+        }
+        // the two rows trade places through LDS (row col lives in thread jj's slot 0)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SPR; ++r) {
+            const int i = c0 + tid + 1024 * r;
+            if (i == col)
+#pragma unroll
+                for (int c = 0; c < W; ++c) s_rowc[c] = a[r][c];
+            if (i == p)
+#pragma unroll
+                for (int c = 0; c < W; ++c) s_rowp[c] = a[r][c];
+        }
+        __syncthreads();
+        const double pv = s_rowp[jj];
+        const double rpv = pv != 0.0 ? 1.0 / pv : 0.0;
+#pragma unroll
+        for (int r = 0; r < SPR; ++r) {
+            const int i = c0 + tid + 1024 * r;
+            if (i == col) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) a[r][c] = s_rowp[c];
+            } else if (i == p) { // p != col here
+#pragma unroll
+                for (int c = 0; c < W; ++c) a[r][c] = s_rowc[c];
+            }
+            if (i > col && i < k) {
+                const double l = a[r][jj] * rpv;
+                a[r][jj] = l;
+#pragma unroll
+                for (int c = 0; c < W; ++c)
+                    if (c > jj) a[r][c] = fma(-l, s_rowp[c], a[r][c]);
+            }
+        }
+        (void)s_p;
+    }
+#pragma unroll
+    for (int r = 0; r < SPR; ++r) {
+        const int i = c0 + tid + 1024 * r;
+        if (i < k)
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (c < w) G[(long long)i * ldg + c0 + c] = a[r][c];
+    }
+    __syncthreads();
+    // the other columns of the enclosing panel: row swaps, then U12' = L11^-1 A12' (as above)
+    const int nother = pnbw - w;
+    if (tid < nother) {
+        const int off = tid < (c0 - pj0) ? tid : tid + w;
+        double *colp = G + pj0 + off;
+        for (int jj = 0; jj < w; ++jj) {
+            const int r = c0 + jj, p = piv[r];
+            if (p != r) {
+                const double x0 = colp[(long long)r * ldg], x1 = colp[(long long)p * ldg];
+                colp[(long long)r * ldg] = x1;
+                colp[(long long)p * ldg] = x0;
+            }
+        }
+        if (pj0 + off >= c0 + w) {
+            double y[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) y[i] = i < w ? colp[(long long)(c0 + i) * ldg] : 0.0;
+#pragma unroll
+            for (int i = 1; i < W; ++i) {
+                double acc = y[i];
+#pragma unroll
+                for (int j = 0; j < W; ++j)
+                    if (j < i && i < w) acc = fma(-G[(long long)(c0 + i) * ldg + c0 + j], y[j], acc);
+                y[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i)
+                if (i < w) colp[(long long)(c0 + i) * ldg] = y[i];
+        }
+    }
+}
+
+// rows [c0 + w, k), panel columns [c0 + w, pj0 + pnbw):  A22' -= L21 * U12'.  One thread per row.
+__global__ __launch_bounds__(256) void k_ref_subupdate(int k, int pj0, int pnbw, int c0, int w,
+                                                       double *__restrict__ G, long long ldg)
+{
+    __shared__ double s_u[SPW][NB];
+    const int right0 = c0 + w, nright = pj0 + pnbw - right0;
+    for (int e = threadIdx.x; e < w * nright; e += blockDim.x)
+        s_u[e / nright][e % nright] = G[(long long)(c0 + e / nright) * ldg + right0 + e % nright];
+    __syncthreads();
+    const int i = right0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    double *row = G + (long long)i * ldg;
+    double l[SPW];
+    for (int j = 0; j < w; ++j) l[j] = row[c0 + j];
+    for (int c = 0; c < nright; ++c) {
+        double acc = row[right0 + c];
+        for (int j = 0; j < w; ++j) acc = fma(-l[j], s_u[j][c], acc);
+        row[right0 + c] = acc;
     }
 }
 
@@ -254,6 +433,7 @@ __global__ __launch_bounds__(256) void k_ref_swap(int k, int j0, int nbw, double
 }
 
 // T[j0..j0+nbw, cbeg..cend) <- L11^-1 T[...]  (unit lower L11 = G[j0.., j0..]); thread per column
+template <bool FULL>
 __global__ __launch_bounds__(256) void k_ref_trsm_l(int j0, int nbw, const double *__restrict__ G,
                                                     long long ldg, double *__restrict__ T,
                                                     long long ldt, int cbeg, int cend)
@@ -264,18 +444,32 @@ __global__ __launch_bounds__(256) void k_ref_trsm_l(int j0, int nbw, const doubl
     __syncthreads();
     const int c = cbeg + blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cend) return;
-    double y[NB];
-#pragma unroll 8
-    for (int i = 0; i < nbw; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
-    for (int i = 1; i < nbw; ++i) {
-        double acc = y[i];
-        for (int j = 0; j < i; ++j) acc = fma(-s_l[i][j], y[j], acc);
-        y[i] = acc;
+    double y[NB]; // FULL: every index below is a compile-time constant, y lives in registers
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
+#pragma unroll
+        for (int i = 1; i < NB; ++i) {
+            double acc = y[i];
+#pragma unroll
+            for (int j = 0; j < i; ++j) acc = fma(-s_l[i][j], y[j], acc);
+            y[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
+    } else {
+        for (int i = 0; i < nbw; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
+        for (int i = 1; i < nbw; ++i) {
+            double acc = y[i];
+            for (int j = 0; j < i; ++j) acc = fma(-s_l[i][j], y[j], acc);
+            y[i] = acc;
+        }
+        for (int i = 0; i < nbw; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
     }
-    for (int i = 0; i < nbw; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
 }
 
 // X[j0..j0+nbw, :) <- U11^-1 X[...]  (upper U11 with diagonal); thread per column
+template <bool FULL>
 __global__ __launch_bounds__(256) void k_ref_trsm_u(int j0, int nbw, const double *__restrict__ G,
                                                     long long ldg, double *__restrict__ X,
                                                     long long ldx, int ncols)
@@ -287,13 +481,27 @@ __global__ __launch_bounds__(256) void k_ref_trsm_u(int j0, int nbw, const doubl
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
     double y[NB];
-    for (int i = 0; i < nbw; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
-    for (int i = nbw - 1; i >= 0; --i) {
-        double acc = y[i];
-        for (int j = i + 1; j < nbw; ++j) acc = fma(-s_u[i][j], y[j], acc);
-        y[i] = acc / s_u[i][i];
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
+#pragma unroll
+        for (int i = NB - 1; i >= 0; --i) {
+            double acc = y[i];
+#pragma unroll
+            for (int j = i + 1; j < NB; ++j) acc = fma(-s_u[i][j], y[j], acc);
+            y[i] = acc / s_u[i][i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
+    } else {
+        for (int i = 0; i < nbw; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
+        for (int i = nbw - 1; i >= 0; --i) {
+            double acc = y[i];
+            for (int j = i + 1; j < nbw; ++j) acc = fma(-s_u[i][j], y[j], acc);
+            y[i] = acc / s_u[i][i];
+        }
+        for (int i = 0; i < nbw; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
     }
-    for (int i = 0; i < nbw; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
 }
 
 // Binv0[spos[b]][a] = X[b][a]   grid (ceil(k/256), k)
@@ -365,16 +573,36 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
         for (int j0 = 0; j0 < k; j0 += NB) {
             const int nbw = (k - j0) < NB ? (k - j0) : NB;
             const int rest = k - j0 - nbw;
-            hipLaunchKernelGGL(k_ref_panel, dim3(1), dim3(1024), 0, st, k, j0, nbw, G, ldg, piv,
-                               singular);
+            // sub-panels: 8 columns while the active rows fit 4 per thread, 4 columns up to 8 rows
+            // per thread (both all-register), the global-memory kernel beyond 8192 active rows
+            for (int c0 = j0; c0 < j0 + nbw;) {
+                const int rows = k - c0;
+                const int cap = rows <= 1024 * 4 ? 8 : (rows <= 1024 * 8 ? 4 : SPW);
+                const int w = (j0 + nbw - c0) < cap ? (j0 + nbw - c0) : cap;
+                if (rows <= 1024 * 4)
+                    hipLaunchKernelGGL((k_ref_subpanel_reg<4, 8>), dim3(1), dim3(1024), 0, st, k, j0,
+                                       nbw, c0, w, G, ldg, piv, singular);
+                else if (rows <= 1024 * 8)
+                    hipLaunchKernelGGL((k_ref_subpanel_reg<8, 4>), dim3(1), dim3(1024), 0, st, k, j0,
+                                       nbw, c0, w, G, ldg, piv, singular);
+                else
+                    hipLaunchKernelGGL(k_ref_subpanel, dim3(1), dim3(1024), 0, st, k, j0, nbw, c0, w,
+                                       G, ldg, piv, singular);
+                const int below = k - c0 - w;
+                if (below > 0 && c0 + w < j0 + nbw)
+                    hipLaunchKernelGGL(k_ref_subupdate, dim3((below + 255) / 256), dim3(256), 0, st,
+                                       k, j0, nbw, c0, w, G, ldg);
+                c0 += w;
+            }
             hipLaunchKernelGGL(k_ref_swap, dim3((2 * k + 255) / 256), dim3(256), 0, st, k, j0, nbw, G,
                                X, ldg, piv);
+            auto trsm_l = nbw == NB ? k_ref_trsm_l<true> : k_ref_trsm_l<false>;
             if (rest > 0) // U12 = L11^-1 A12
-                hipLaunchKernelGGL(k_ref_trsm_l, dim3((rest + 255) / 256), dim3(256), 0, st, j0, nbw,
-                                   G, ldg, G, ldg, j0 + nbw, k);
+                hipLaunchKernelGGL(trsm_l, dim3((rest + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, G,
+                                   ldg, j0 + nbw, k);
             // forward substitution block of X (all k columns)
-            hipLaunchKernelGGL(k_ref_trsm_l, dim3((k + 255) / 256), dim3(256), 0, st, j0, nbw, G, ldg,
-                               X, ldg, 0, k);
+            hipLaunchKernelGGL(trsm_l, dim3((k + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, X, ldg,
+                               0, k);
             if (rest > 0) {
                 const double *L21 = G + (long long)(j0 + nbw) * ldg + j0;
                 // A22 -= L21 * U12
@@ -389,8 +617,8 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
         const int last = ((k - 1) / NB) * NB;
         for (int j0 = last; j0 >= 0; j0 -= NB) {
             const int nbw = (k - j0) < NB ? (k - j0) : NB;
-            hipLaunchKernelGGL(k_ref_trsm_u, dim3((k + 255) / 256), dim3(256), 0, st, j0, nbw, G, ldg, X,
-                               ldg, k);
+            auto trsm_u = nbw == NB ? k_ref_trsm_u<true> : k_ref_trsm_u<false>;
+            hipLaunchKernelGGL(trsm_u, dim3((k + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, X, ldg, k);
             if (j0 > 0) // X[0..j0) -= U01 * X1
                 gemm_sub(j0, k, nbw, G + j0, ldg, X + (long long)j0 * ldg, ldg, X, ldg, st);
         }
