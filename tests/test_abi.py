@@ -211,3 +211,23 @@ def test_plain_c_host_solves_the_readme_lp(tmp_path):
     assert float(l1["objective"]) == want.objective           # STRICT: bit-identical
     k, e, l, _ = want.pivots[0]
     assert l1["first_pivot"] == f"{k}:{e}:{l}"
+
+
+def test_reference_package_name_resolves_to_this_implementation():
+    """`import dantzig`, `dantzig.rust`, `from dantzig.model import ...` (the names the reference's
+    callers use: python-source/dantzig/model.py:5, optimize.py:4) are this repo's objects."""
+    import dantzig
+    import dantzig.exceptions
+    import dantzig.rust
+    import dantzig_amd
+    from dantzig import rust as rs
+    from dantzig.model import Variable
+
+    assert dantzig.rust is dantzig_amd.rust is rs
+    assert Variable is dantzig_amd.Variable is dantzig.Var
+    assert dantzig.Minimize is dantzig_amd.Minimize and dantzig.Max is dantzig_amd.Maximize
+    assert dantzig.exceptions.UnboundedError is dantzig_amd.exceptions.UnboundedError
+    assert set(dantzig.__all__) == {"Variable", "Var", "Minimize", "Min", "Maximize", "Max",
+                                    "exceptions"}
+    for name in ("Variable", "PyLinExpr", "PyAffExpr", "PyInequality", "PySolution", "solve"):
+        assert hasattr(dantzig.rust, name)          # src/lib.rs:29-38

@@ -59,3 +59,32 @@ def test_bench_fails_loudly_without_a_gpu():
     assert run.returncode != 0
     assert "no HIP device" in run.stderr or "no CPU" in run.stderr
     assert run.stdout.strip() == ""  # no JSON line is ever printed for a run that measured nothing
+
+
+def test_profiler_child_is_killed_with_its_whole_process_group(tmp_path):
+    """pmc_traffic's children run in their own process group and a timeout ends the group: the
+    profiled program is rocprofv3's grandchild and must not outlive it on the GPU."""
+    import time
+
+    bench = _bench()
+    marker = tmp_path / "grandchild.pid"
+    script = ("import os, subprocess, sys, time\n"
+              f"p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)'])\n"
+              f"open({str(marker)!r}, 'w').write(str(p.pid))\n"
+              "time.sleep(60)\n")
+    t0 = time.time()
+    try:
+        bench._run_in_own_group([sys.executable, "-c", script], str(tmp_path), dict(os.environ), 2)
+        raise AssertionError("expected a timeout")
+    except subprocess.TimeoutExpired:
+        pass
+    assert time.time() - t0 < 30
+    pid = int(marker.read_text())
+    for _ in range(50):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the grandchild survived the timeout")

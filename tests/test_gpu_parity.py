@@ -726,3 +726,28 @@ def test_tree_pricing_does_not_depend_on_its_launch_shape(core):
     got = core.neg_t_dot(a2, cols2, v2, kernel=core.PRICE_TREE)
     want = np.array([-(a2[:, j] @ v2) if j >= 0 else -v2[-1 - j] for j in cols2])
     assert np.allclose(got, want, rtol=0, atol=1e-13)
+
+
+# ------------------------------------------------------------------ refactorisation policy
+def test_refactor_workspace_is_reserved_on_first_need(core):
+    """refactor_interval = 0 reserves nothing at creation, yet the solver can still rebuild its
+    inverse (dzg_solver_refactor reserves the workspace lazily -- what the pivot-consistency
+    monitor relies on to recover instead of stopping with DZG_SINGULAR); the rebuilt inverse
+    carries the solve on along the oracle's pivots, and the health monitor restarts with it:
+    one refactorisation stays one, it is not repeated batch after batch."""
+    a, b, c = core.gen_dense_lp(seed=91, m=96, n_struct=200)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    with core.Solver(lp, numerics=core.FAST, poll_interval=8) as s:
+        assert s.run(150) == "iter_limit"
+        before = s.result(log=False)
+        assert before.refactors == 0 and before.max_pivot_error > 0.0
+        s.refactor()
+        assert s.run(40) == "iter_limit"
+        mid = s.result(log=False)
+        assert mid.refactors == 1
+        assert s.run(0) == want.status == "optimal"
+        res = s.result()
+    assert res.refactors == 1                       # no refactorisation per batch afterwards
+    assert res.max_pivot_error >= before.max_pivot_error   # the reported maximum is lifetime
+    assert _log(res) == _log(want)

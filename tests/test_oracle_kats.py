@@ -159,3 +159,22 @@ def test_optimality_certificate_agrees_with_the_oracle():
         early = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=max(1, res.iterations // 2))
         bad = certificate(a, b, c, early.basis)
         assert bad["primal_infeas"] > 1e-9 or bad["dual_infeas"] > 1e-9
+
+
+def test_integer_lp_fixture_is_the_oracle():
+    """tests/golden/integer_lps_200_400.json (what the GPU suite holds AUTO numerics to) really is
+    the oracle's outcome: a sample of its cases is recomputed here."""
+    import json
+    import os
+
+    from tests.lp_families import log_digest, make_lp
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "integer_lps_200_400.json")) as f:
+        fx = json.load(f)
+    assert len(fx["cases"]) >= 200 and {c["kind"] for c in fx["cases"]} == {1, 2}
+    assert all(fx["min_m"] <= c["m"] < fx["max_m"] for c in fx["cases"])
+    for case in fx["cases"][::29]:
+        a, b, c = make_lp(case["seed"], case["kind"], fx["min_m"], fx["max_m"])
+        r = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=fx["cap"])
+        assert (r.status, r.iterations, log_digest(r.pivots)) == (case["status"], case["pivots"],
+                                                                  case["sha256"])
