@@ -87,7 +87,7 @@ __device__ __forceinline__ int shard_merge(const double *__restrict__ xrecv, lon
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fast_select_prep(
     DzgCtl *ctl, int m, const double *__restrict__ A, long long lda, int col0,
-    const double *__restrict__ xrecv, long long xstride, int need_kind,
+    const double *__restrict__ xrecv, long long xstride,
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ fpx_r, const int *__restrict__ fpx_k,
     const double *__restrict__ fpx_h, const double *__restrict__ fpz_r,
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
 {
     DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
-    const double inf = __builtin_inf();
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     int epos;
     int code_known = 0, code_val = -1;
@@ -124,11 +123,6 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
             c.enter_src = w;
             if (lead) ctl->enter_src = w;
         }
-    } else if (MODE == 2) { // selection already published in the control block
-        if (c.kind != need_kind) return;
-        epos = c.enter_pos;
-        code_known = 1;
-        code_val = c.enter_code;
     } else if (MODE == 5) {
         // column sharding, second exchange.  Dual step: merge the ratio-test proposals (none =
         // Infeasible, src/simplex.rs:325), take the entering column and z, zbar, dz from the
@@ -184,7 +178,7 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
     }
     // ---- FTRAN preparation for the entering variable
     const int code = code_known ? code_val : var_col[nonbasis[epos]];
-    if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
     const double *a = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
     const int neta = c.neta, k = c.ncompact;
     const int b = blockIdx.x;
@@ -699,7 +693,6 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
     // single workgroup: the structural-position list must be built in position order
     for (int r = threadIdx.x; r < m; r += blockDim.x) dslot[r] = -1;
     __syncthreads();
-    __shared__ int s_count;
     if (threadIdx.x == 0) {
         int s = 0;
         for (int k = 0; k < q; ++k) {
@@ -712,7 +705,6 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
                 pslot[k] = -1;
             }
         }
-        s_count = s;
         long long nnz = 0;
         if (cptr)
             for (int i = 0; i < s; ++i) {
@@ -830,19 +822,16 @@ void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const doubl
                                  hipStream_t st)
 {
     // mode 0: status + primal prep          1: dual ratio test + prep          (one GPU)
-    //      2/3: prep only, selection already in the control block
     //      4: merge proposals + status + primal prep     5: merge second exchange + dual prep
-#define SEL_ARGS(need) d.ctl, d.m, d.A, d.lda, d.col0, xrecv, d.xstride, need, d.nonbasis, d.var_col,    \
+#define SEL_ARGS d.ctl, d.m, d.A, d.lda, d.col0, xrecv, d.xstride, d.nonbasis, d.var_col,                \
                        d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.rz_r, d.rz_k, d.rz_h, nrz,  \
                        d.W, d.ldw, d.drow, d.ag, d.beta, d.eps, d.world
     const dim3 grid(R_ + 1), block(256);
     switch (mode) {
-    case 0: hipLaunchKernelGGL((k_fast_select_prep<0>), grid, block, 0, st, SEL_ARGS(0)); break;
-    case 1: hipLaunchKernelGGL((k_fast_select_prep<1>), grid, block, 0, st, SEL_ARGS(0)); break;
-    case 2: hipLaunchKernelGGL((k_fast_select_prep<2>), grid, block, 0, st, SEL_ARGS(DZG_STEP_PRIMAL)); break;
-    case 3: hipLaunchKernelGGL((k_fast_select_prep<2>), grid, block, 0, st, SEL_ARGS(DZG_STEP_DUAL)); break;
-    case 4: hipLaunchKernelGGL((k_fast_select_prep<4>), grid, block, 0, st, SEL_ARGS(0)); break;
-    default: hipLaunchKernelGGL((k_fast_select_prep<5>), grid, block, 0, st, SEL_ARGS(0)); break;
+    case 0: hipLaunchKernelGGL((k_fast_select_prep<0>), grid, block, 0, st, SEL_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_fast_select_prep<1>), grid, block, 0, st, SEL_ARGS); break;
+    case 4: hipLaunchKernelGGL((k_fast_select_prep<4>), grid, block, 0, st, SEL_ARGS); break;
+    default: hipLaunchKernelGGL((k_fast_select_prep<5>), grid, block, 0, st, SEL_ARGS); break;
     }
 #undef SEL_ARGS
 }

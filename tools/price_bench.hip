@@ -100,5 +100,10 @@ int main(int argc, char **argv)
     }
 #define WAVE2(U, BLK) time_it("wave2<" #U "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_wave2<U>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr, nullptr); }, true)
     WAVE2(4, 2048); WAVE2(4, 4096);
+    // round 2: the register-accumulator kernel in every shape (its results do not depend on it)
+#define TREE(CW, DEP, BLK) time_it("tree<" #CW "," #DEP "> x" #BLK, [&] { hipLaunchKernelGGL((k_price_tree<CW, DEP>), dim3(BLK), dim3(256), 0, 0, ARGS, dz, nullptr, nullptr, nullptr, nullptr, nullptr); }, true)
+    TREE(16, 2, 256); TREE(16, 3, 256); TREE(16, 4, 256); TREE(8, 4, 256); TREE(8, 4, 512); TREE(8, 6, 512);
+    TREE(4, 8, 256); TREE(4, 8, 1024); TREE(4, 4, 1024); TREE(2, 16, 256); TREE(2, 8, 2048); TREE(1, 16, 2048);
+    TREE(16, 2, 512); TREE(8, 8, 256);
     return 0;
 }
