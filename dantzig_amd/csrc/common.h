@@ -37,7 +37,7 @@ struct DzgCtl {
     int enter_src;       // sharded: rank whose exchange record carries the entering column
     // sharded: z, zbar, dz of the entering position as published by its owner
     double zr, zbar_r, dz_r;
-    int use_record;      // 1: k_fast_pivot takes zr/zbar_r/dz_r instead of its local z arrays
+    int use_record;      // 1: fast_pivot_books takes zr/zbar_r/dz_r instead of its local z arrays
     int del_last;        // >= 0: k_fast_update deletes a compact column of Binv0 (an entering
     int del_ce;          //       slack): column del_ce := column del_last, column del_last := 0
     int pad2;
@@ -62,6 +62,10 @@ struct DzgCtl {
     int sp_mrow;          // >= 0: row sp_k-1 of X moves into this row
     int sp_mcol;          // >= 0: column sp_k-1 of X moves into this column
     int sp_zcol;          // >= 0: column slot recycled for another row: cleared
+    // dense path: the pivot's books are kept inside the dual-step GEMV launch, whose other
+    // workgroups may still be reading neta / ncompact: the new values wait here until
+    // k_fast_update (the next launch) commits them
+    int neta_next, ncompact_next;
     int pad3;
 };
 
@@ -390,7 +394,6 @@ void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const doubl
                                  hipStream_t st);
 void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, hipStream_t st);
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st);
-void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st);
 void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st);
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st);
 void dzg_launch_refactor_lists(const DzgDev &d, int *spos, int *scode, int *lpos, int *lrow,

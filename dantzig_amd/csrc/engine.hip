@@ -566,8 +566,7 @@ static void enqueue_fast_iteration(dzg_solver *s, int slot)
     dzg_launch_fast_gemv(d, DZG_STEP_DUAL, nullptr, st);                    // dual step: dx last
     pf.end(DZG_K_RATIO);
     pf.begin(DZG_K_UPDATE);
-    dzg_launch_fast_pivot(d, st);
-    dzg_launch_fast_update(d, 0, st);
+    dzg_launch_fast_update(d, 0, st); // (the pivot's books were kept by the launch before)
     pf.end(DZG_K_UPDATE);
     if (++s->since_flush >= DZG_RMAX) {
         pf.begin(DZG_K_BASIS_UPDATE);
@@ -943,8 +942,7 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
     hipStream_t st = s->st;
     phase_stamp(s, DZG_K_UPDATE, 0);
     dzg_launch_fast_select_prep(d, 5, 0, recv_dev, st);    // merge + (dual) FTRAN prep
-    dzg_launch_fast_gemv(d, DZG_STEP_DUAL, recv_dev, st);
-    dzg_launch_fast_pivot(d, st);
+    dzg_launch_fast_gemv(d, DZG_STEP_DUAL, recv_dev, st); // + the pivot's books
     dzg_launch_fast_update(d, 0, st);
     if (++s->since_flush >= DZG_RMAX) {
         dzg_launch_fast_flush(d, st);

@@ -42,7 +42,7 @@ __device__ __forceinline__ bool tie_gate(DzgCtl *ctl, const DzgCtl &c, bool lead
 }
 
 // A terminal verdict (optimal / unbounded / infeasible) taken inside the tolerance executes no
-// pivot, so k_fast_pivot never books it: count it here.
+// pivot, so fast_pivot_books never books it: count it here.
 __device__ __forceinline__ void tie_book_terminal(DzgCtl *ctl, const DzgCtl &c, double margin)
 {
     if (!(margin > c.tau)) {

@@ -213,168 +213,46 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
 }
 
 // ---------------------------------------------------------------------------------
-// k_fast_gemv: dx = Binv a_j.  LPR lanes cooperate on one row (64 when the compact width k is
-// large, 16 when it is small so that a wave covers 4 rows per pass).  A primal step also leaves
-// the per-workgroup ratio-test candidates (src/simplex.rs:439-461) for k_fast_btran.
-// grid = DZG_NB_GEMV workgroups of 256.
-// ---------------------------------------------------------------------------------
-template <int LPR>
-__device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int m, int k, int neta,
-                                          int code, const double *__restrict__ binv,
-                                          long long ldb, const double *__restrict__ ag,
-                                          const double *__restrict__ U, long long ldu,
-                                          const double *__restrict__ beta,
-                                          const double *__restrict__ acolp,
-                                          const int *__restrict__ basis,
-                                          const int *__restrict__ var_col,
-                                          const double *__restrict__ x,
-                                          const double *__restrict__ xbar,
-                                          double *__restrict__ dx, DzgCand2 &best)
-{
-    constexpr int RPW = 64 / LPR; // rows per wave and pass
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPR, grp = lane / LPR;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int k2 = (k + 1) & ~1;
-    const double mu = ctl->mu, tau = ctl->tau;
-    for (int i0 = wave_global * RPW; i0 < m; i0 += nwaves * RPW) {
-        const int i = i0 + grp;
-        double acc = 0.0;
-        if (i < m) {
-            const double *row = binv + (long long)i * ldb;
-            double a0 = 0.0, a1 = 0.0;
-            int c = 2 * sub;
-            for (; c + 2 * LPR < k2; c += 4 * LPR) {
-                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-                const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 2 * LPR);
-                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
-                const double2_t g1 = *reinterpret_cast<const double2_t *>(ag + c + 2 * LPR);
-                a0 = fma(r0.x, g0.x, a0);
-                a1 = fma(r1.x, g1.x, a1);
-                a0 = fma(r0.y, g0.y, a0);
-                a1 = fma(r1.y, g1.y, a1);
-            }
-            for (; c < k2; c += 2 * LPR) {
-                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
-                a0 = fma(r0.x, g0.x, a0);
-                a0 = fma(r0.y, g0.y, a0);
-            }
-            acc = a0 + a1;
-            for (int t = sub; t < neta; t += LPR) acc = fma(-U[(long long)t * ldu + i], beta[t], acc);
-        }
-#pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
-        if (i < m && sub == 0) {
-            const int bc = var_col[basis[i]];
-            if (bc < 0) { // position i holds the slack of row rr: unit column contributes a_j[rr]
-                const int rr = -1 - bc;
-                acc += code >= 0 ? acolp[rr] : ((-1 - code) == rr ? 1.0 : 0.0);
-            }
-            dx[i] = acc;
-            if (need_kind == DZG_STEP_PRIMAL) {
-                const double xi = x[i], scaled = mu * xbar[i];
-                const double den = xi + scaled;
-                DzgCand2 cnd;
-                cnd.r = dzg_div(acc, den);
-                cnd.k = i;
-                cnd.h = -__builtin_inf();
-                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
-                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_fast_gemv(
-    const DzgCtl *ctl, int need_kind, int m, const double *__restrict__ binv, long long ldb,
-    const double *__restrict__ ag, const double *__restrict__ U, long long ldu,
-    const double *__restrict__ beta, const double *__restrict__ A, long long lda, int col0,
-    const double *__restrict__ xrecv, long long xstride, const int *__restrict__ basis,
-    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
-    const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
-    double *__restrict__ rx_r, int *__restrict__ rx_k, double *__restrict__ rx_h)
-{
-    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
-    if (c.status != DZG_RUNNING || c.kind != need_kind) return;
-    const int k = c.ncompact, neta = c.neta;
-    const int code = c.enter_code;
-    const double *acolp = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
-    DzgCand2 best = dzg_cand2_none();
-    if (k > 512)
-        gemv_rows<64>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
-                      var_col, x, xbar, dx, best);
-    else
-        gemv_rows<16>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
-                      var_col, x, xbar, dx, best);
-    if (need_kind == DZG_STEP_PRIMAL) {
-        best = dzg_block_best2(best);
-        if (threadIdx.x == 0) {
-            rx_r[blockIdx.x] = best.r;
-            rx_k[blockIdx.x] = best.k;
-            rx_h[blockIdx.x] = best.h;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// k_fast_btran: v = row p of Binv.  A primal step first finishes its ratio test (leaving
-// position p = argmax over the GEMV partials; none = Unbounded, src/simplex.rs:313).
-// grid = ceil(m / 256) workgroups of 256.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fast_btran(
-    DzgCtl *ctl, int m, const double *__restrict__ binv, long long ldb,
-    const int *__restrict__ dslot, const int *__restrict__ basis, const int *__restrict__ var_col,
-    const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
-    const double *__restrict__ rx_r, const int *__restrict__ rx_k,
-    const double *__restrict__ rx_h, double *__restrict__ v)
-{
-    __shared__ double s_up[R_];
-    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
-    if (c.status != DZG_RUNNING) return;
-    int p;
-    if (c.kind == DZG_STEP_PRIMAL) {
-        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-        const DzgCand2 cw = reduce_partials(rx_r, rx_k, rx_h, DZG_NB_GEMV);
-        if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_UNBOUNDED)) return; // :313
-        p = cw.k;
-        if (lead) ctl->leave_pos = p;
-    } else {
-        p = c.leave_pos;
-    }
-    const int neta = c.neta;
-    if (threadIdx.x < R_) s_up[threadIdx.x] = threadIdx.x < neta ? U[(long long)threadIdx.x * ldu + p] : 0.0;
-    __syncthreads();
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= m) return;
-    const int slot = dslot[r];
-    const double base = slot >= 0 ? binv[(long long)p * ldb + slot]
-                                  : (var_col[basis[p]] == -1 - r ? 1.0 : 0.0);
-    double acc = 0.0;
-    for (int t = 0; t < neta; ++t) acc = fma(s_up[t], W[(long long)t * ldw + r], acc);
-    v[r] = base - acc;
-}
-
-// ---------------------------------------------------------------------------------
-// k_fast_pivot: step lengths and the finiteness assert (src/simplex.rs:257-260,:464-468), swap
+// fast_pivot_books: step lengths and the finiteness assert (src/simplex.rs:257-260,:464-468), swap
 // (:239-251), pivot log, then the basis bookkeeping: eta append, compact column append /
-// delete, list of nonbasic structural positions.  One workgroup of 1024.
+// delete, list of nonbasic structural positions.  Work for ONE workgroup; it has no kernel of its
+// own: it runs in the dual-step launch of k_fast_gemv, which precedes the update kernel in every
+// iteration -- as workgroup 0 in a primal step (that launch has nothing else to do then: dx, dz,
+// p and r are all known), as the LAST workgroup to finish its rows of dx in a dual step.
+// `c` is the control block as that kernel found it.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_fast_pivot(
-    DzgCtl *ctl, int m, int q, const double *__restrict__ x, const double *__restrict__ xbar,
-    const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dx,
-    const double *__restrict__ dz, const double *__restrict__ v, int *basis, int *nonbasis,
-    const int *__restrict__ var_col, double *binv, long long ldb, int *drow, int *dslot,
-    double *U, long long ldu, double *W, long long ldw, int *plist, int *pslot, int col0, int col1,
-    const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
-    double *log_mu, double *log_margin, long long log_cap)
+struct DzgPivotArgs {
+    int m, q;
+    const double *x, *xbar, *z, *zbar, *dx, *dz, *v;
+    int *basis, *nonbasis;
+    const int *var_col;
+    double *binv;
+    long long ldb;
+    int *drow, *dslot;
+    double *W;
+    long long ldw;
+    int *plist, *pslot;
+    int col0, col1;
+    const long long *cptr;
+    int *log_kind, *log_enter, *log_leave;
+    double *log_mu, *log_margin;
+    long long log_cap;
+};
+
+__device__ __forceinline__ void fast_pivot_books(DzgCtl *ctl, const DzgCtl &c, const DzgPivotArgs &pa,
+                                                 double dxp)
 {
     __shared__ int s_ok, s_k, s_ci, s_cj;
-    // hop 1: the whole control block in one go (a couple of cache lines); every later decision
-    // uses this snapshot, and only the fields that change are written back at the end
-    const DzgCtl c = *ctl;
-    if (c.status != DZG_RUNNING) return;
+    const int m = pa.m, q = pa.q, col0 = pa.col0, col1 = pa.col1;
+    const double *x = pa.x, *xbar = pa.xbar, *z = pa.z, *zbar = pa.zbar, *dz = pa.dz;
+    int *basis = pa.basis, *nonbasis = pa.nonbasis, *drow = pa.drow, *dslot = pa.dslot;
+    int *plist = pa.plist, *pslot = pa.pslot;
+    const int *var_col = pa.var_col;
+    double *binv = pa.binv, *W = pa.W;
+    const long long ldb = pa.ldb, ldw = pa.ldw, log_cap = pa.log_cap;
+    const long long *cptr = pa.cptr;
+    int *log_kind = pa.log_kind, *log_enter = pa.log_enter, *log_leave = pa.log_leave;
+    double *log_mu = pa.log_mu, *log_margin = pa.log_margin;
     const int tid = threadIdx.x;
     const int p = c.leave_pos, r = c.enter_pos, neta = c.neta;
     const bool rec = c.use_record != 0;
@@ -385,7 +263,7 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     if (tid == 0) {
         vi = basis[p];
         vj = nonbasis[r];
-        const double xp = x[p], xbp = xbar[p], dxp = dx[p];
+        const double xp = x[p], xbp = xbar[p]; // (dx_p comes from the workgroup's own GEMV row)
         const double zr = rec ? c.zr : z[r], zbr = rec ? c.zbar_r : zbar[r];
         const double dzr = rec ? c.dz_r : dz[r];
         idx_r = pslot[r];
@@ -493,10 +371,10 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
     ctl->nb_struct = s;
     ctl->enter_var = vj;
     ctl->leave_var = vi;
-    ctl->ncompact = s_k;
+    ctl->ncompact_next = s_k; // committed by k_fast_update: this launch still reads the old ones
     ctl->del_ce = del_ce;
     ctl->del_last = del_last;
-    ctl->neta = neta + 1;
+    ctl->neta_next = neta + 1;
     ctl->max_pivot_err = max_err;
     // near-tie record of this pivot; the tolerance follows the health monitor
     if (it < log_cap) log_margin[it] = c.margin;
@@ -513,11 +391,177 @@ __global__ __launch_bounds__(1024) void k_fast_pivot(
 }
 
 // ---------------------------------------------------------------------------------
+// k_fast_gemv: dx = Binv a_j.  LPR lanes cooperate on one row (64 when the compact width k is
+// large, 16 when it is small so that a wave covers 4 rows per pass).  A primal step also leaves
+// the per-workgroup ratio-test candidates (src/simplex.rs:439-461) for k_fast_btran.
+// grid = DZG_NB_GEMV workgroups of 256.
+// ---------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int m, int k, int neta,
+                                          int code, const double *__restrict__ binv,
+                                          long long ldb, const double *__restrict__ ag,
+                                          const double *__restrict__ U, long long ldu,
+                                          const double *__restrict__ beta,
+                                          const double *__restrict__ acolp,
+                                          const int *__restrict__ basis,
+                                          const int *__restrict__ var_col,
+                                          const double *__restrict__ x,
+                                          const double *__restrict__ xbar,
+                                          double *__restrict__ dx, DzgCand2 &best, int want_row,
+                                          double *want_dx)
+{
+    constexpr int RPW = 64 / LPR; // rows per wave and pass
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int k2 = (k + 1) & ~1;
+    const double mu = ctl->mu, tau = ctl->tau;
+    for (int i0 = wave_global * RPW; i0 < m; i0 += nwaves * RPW) {
+        const int i = i0 + grp;
+        double acc = 0.0;
+        if (i < m) {
+            const double *row = binv + (long long)i * ldb;
+            double a0 = 0.0, a1 = 0.0;
+            int c = 2 * sub;
+            for (; c + 2 * LPR < k2; c += 4 * LPR) {
+                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
+                const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 2 * LPR);
+                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+                const double2_t g1 = *reinterpret_cast<const double2_t *>(ag + c + 2 * LPR);
+                a0 = fma(r0.x, g0.x, a0);
+                a1 = fma(r1.x, g1.x, a1);
+                a0 = fma(r0.y, g0.y, a0);
+                a1 = fma(r1.y, g1.y, a1);
+            }
+            for (; c < k2; c += 2 * LPR) {
+                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
+                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+                a0 = fma(r0.x, g0.x, a0);
+                a0 = fma(r0.y, g0.y, a0);
+            }
+            acc = a0 + a1;
+            for (int t = sub; t < neta; t += LPR) acc = fma(-U[(long long)t * ldu + i], beta[t], acc);
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+        if (i < m && sub == 0) {
+            const int bc = var_col[basis[i]];
+            if (bc < 0) { // position i holds the slack of row rr: unit column contributes a_j[rr]
+                const int rr = -1 - bc;
+                acc += code >= 0 ? acolp[rr] : ((-1 - code) == rr ? 1.0 : 0.0);
+            }
+            dx[i] = acc;
+            if (i == want_row) *want_dx = acc; // (LDS: the row whose dx the pivot's books need)
+            if (need_kind == DZG_STEP_PRIMAL) {
+                const double xi = x[i], scaled = mu * xbar[i];
+                const double den = xi + scaled;
+                DzgCand2 cnd;
+                cnd.r = dzg_div(acc, den);
+                cnd.k = i;
+                cnd.h = -__builtin_inf();
+                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
+            }
+        }
+    }
+}
+
+template <bool PIVOT>
+__global__ __launch_bounds__(256) void k_fast_gemv(
+    DzgCtl *ctl, int need_kind, int m, const double *__restrict__ binv, long long ldb,
+    const double *__restrict__ ag, const double *__restrict__ U, long long ldu,
+    const double *__restrict__ beta, const double *__restrict__ A, long long lda, int col0,
+    const double *__restrict__ xrecv, long long xstride, const int *__restrict__ basis,
+    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
+    double *__restrict__ rx_r, int *__restrict__ rx_k, double *__restrict__ rx_h,
+    DzgPivotArgs pa)
+{
+    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    if (c.status != DZG_RUNNING) return;
+    __shared__ double s_dxp;
+    if (c.kind != need_kind) {
+        // PIVOT (the dual-step launch) in a primal step: dx has been there since the primal
+        // launch, the ratio tests are done: workgroup 0 keeps the books of the pivot
+        if (PIVOT && blockIdx.x == 0) fast_pivot_books(ctl, c, pa, dx[c.leave_pos]);
+        return;
+    }
+    const int k = c.ncompact, neta = c.neta;
+    const int code = c.enter_code;
+    const double *acolp = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
+    DzgCand2 best = dzg_cand2_none();
+    // dual step: the workgroup that computes row p of dx keeps the books right after (no other
+    // workgroup's result is needed, so no device-wide synchronisation: a release fence of 512
+    // workgroups costs ~30 us here)
+    const int p = PIVOT ? c.leave_pos : -1;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int rpw = k > 512 ? 1 : 4;
+    const bool owner = PIVOT && ((p / rpw) % nwaves) / (int)(blockDim.x >> 6) == (int)blockIdx.x;
+    if (k > 512)
+        gemv_rows<64>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
+                      var_col, x, xbar, dx, best, p, &s_dxp);
+    else
+        gemv_rows<16>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
+                      var_col, x, xbar, dx, best, p, &s_dxp);
+    if (need_kind == DZG_STEP_PRIMAL) {
+        best = dzg_block_best2(best);
+        if (threadIdx.x == 0) {
+            rx_r[blockIdx.x] = best.r;
+            rx_k[blockIdx.x] = best.k;
+            rx_h[blockIdx.x] = best.h;
+        }
+    }
+    if (owner) { // block-uniform
+        __syncthreads();
+        fast_pivot_books(ctl, c, pa, s_dxp);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_fast_btran: v = row p of Binv.  A primal step first finishes its ratio test (leaving
+// position p = argmax over the GEMV partials; none = Unbounded, src/simplex.rs:313).
+// grid = ceil(m / 256) workgroups of 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_btran(
+    DzgCtl *ctl, int m, const double *__restrict__ binv, long long ldb,
+    const int *__restrict__ dslot, const int *__restrict__ basis, const int *__restrict__ var_col,
+    const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
+    const double *__restrict__ rx_r, const int *__restrict__ rx_k,
+    const double *__restrict__ rx_h, double *__restrict__ v)
+{
+    __shared__ double s_up[R_];
+    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    if (c.status != DZG_RUNNING) return;
+    int p;
+    if (c.kind == DZG_STEP_PRIMAL) {
+        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+        const DzgCand2 cw = reduce_partials(rx_r, rx_k, rx_h, DZG_NB_GEMV);
+        if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_UNBOUNDED)) return; // :313
+        p = cw.k;
+        if (lead) ctl->leave_pos = p;
+    } else {
+        p = c.leave_pos;
+    }
+    const int neta = c.neta;
+    if (threadIdx.x < R_) s_up[threadIdx.x] = threadIdx.x < neta ? U[(long long)threadIdx.x * ldu + p] : 0.0;
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int slot = dslot[r];
+    const double base = slot >= 0 ? binv[(long long)p * ldb + slot]
+                                  : (var_col[basis[p]] == -1 - r ? 1.0 : 0.0);
+    double acc = 0.0;
+    for (int t = 0; t < neta; ++t) acc = fma(s_up[t], W[(long long)t * ldw + r], acc);
+    v[r] = base - acc;
+}
+
+// ---------------------------------------------------------------------------------
 // k_fast_update: pivot() x4 (src/simplex.rs:262-265, :410-421) and, on the updated values, the
 // per-workgroup first-pivot candidates of the NEXT iteration (src/simplex.rs:423-437).
 // grid = DZG_NB_UPD workgroups of 256.  only_partials != 0: no update (initial state).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only_partials, double *x,
+__global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_partials, double *x,
                                                      double *xbar, double *z, double *zbar,
                                                      const double *__restrict__ dx,
                                                      const double *__restrict__ dz, int m, int q,
@@ -534,7 +578,7 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
     const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
     const int p = c.leave_pos, r = c.enter_pos;
-    if (!only_partials && c.del_last >= 0) { // compact column delete booked by k_fast_pivot
+    if (!only_partials && c.del_last >= 0) { // compact column delete booked by fast_pivot_books
         const int ce = c.del_ce, last = c.del_last;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
             double *row = binv + (long long)i * ldb;
@@ -542,9 +586,16 @@ __global__ __launch_bounds__(256) void k_fast_update(const DzgCtl *ctl, int only
             row[last] = 0.0;
         }
     }
-    // eta of the pivot k_fast_pivot just booked (neta already counts it): u = (dx - e_p)/dx_p,
+    // eta of the pivot fast_pivot_books just booked (neta_new counts it): u = (dx - e_p)/dx_p,
     // w = v; if a slack entered, its row of W is structurally zero (its column became e_p)
-    const int teta = c.neta - 1;
+    // the pivot's books (kept inside the previous launch) left the new eta / column counts in
+    // *_next; this kernel works with them and commits them
+    const int neta_new = only_partials ? c.neta : c.neta_next;
+    if (!only_partials && blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->neta = c.neta_next;
+        ctl->ncompact = c.ncompact_next;
+    }
+    const int teta = neta_new - 1;
     const int wzero = c.enter_code < 0 ? -1 - c.enter_code : -1;
     const double rdxp = only_partials ? 0.0 : 1.0 / dx[p];
     double *ut = U + (long long)(teta < 0 ? 0 : teta) * ldu;
@@ -836,11 +887,26 @@ void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const doubl
 #undef SEL_ARGS
 }
 
+// need_kind == DZG_STEP_DUAL is the launch right before k_fast_update in every iteration: it also
+// keeps the books of the pivot (fast_pivot_books), whatever the step kind.
 void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fast_gemv, dim3(DZG_NB_GEMV), dim3(256), 0, st, d.ctl, need_kind, d.m,
-                       d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.col0, xrecv, d.xstride,
-                       d.basis, d.nonbasis, d.var_col, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h);
+    DzgPivotArgs pa;
+    pa.m = d.m; pa.q = d.q;
+    pa.x = d.x; pa.xbar = d.xbar; pa.z = d.z; pa.zbar = d.zbar; pa.dx = d.dx; pa.dz = d.dz; pa.v = d.v;
+    pa.basis = d.basis; pa.nonbasis = d.nonbasis; pa.var_col = d.var_col;
+    pa.binv = d.binv; pa.ldb = d.ldb; pa.drow = d.drow; pa.dslot = d.dslot;
+    pa.W = d.W; pa.ldw = d.ldw; pa.plist = d.plist; pa.pslot = d.pslot;
+    pa.col0 = d.col0; pa.col1 = d.col1; pa.cptr = d.csc ? d.cptr : nullptr;
+    pa.log_kind = d.log_kind; pa.log_enter = d.log_enter; pa.log_leave = d.log_leave;
+    pa.log_mu = d.log_mu; pa.log_margin = d.log_margin; pa.log_cap = d.log_cap;
+#define GEMV_ARGS d.ctl, need_kind, d.m, d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.col0, xrecv,  \
+                  d.xstride, d.basis, d.nonbasis, d.var_col, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h, pa
+    if (need_kind == DZG_STEP_DUAL)
+        hipLaunchKernelGGL((k_fast_gemv<true>), dim3(DZG_NB_GEMV), dim3(256), 0, st, GEMV_ARGS);
+    else
+        hipLaunchKernelGGL((k_fast_gemv<false>), dim3(DZG_NB_GEMV), dim3(256), 0, st, GEMV_ARGS);
+#undef GEMV_ARGS
 }
 
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
@@ -848,16 +914,6 @@ void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_fast_btran, dim3((d.m + 255) / 256), dim3(256), 0, st, d.ctl, d.m, d.binv,
                        d.ldb, d.dslot, d.basis, d.var_col, d.U, d.ldw, d.W, d.ldw, d.rx_r, d.rx_k, d.rx_h,
                        d.v);
-}
-
-void dzg_launch_fast_pivot(const DzgDev &d, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_fast_pivot, dim3(1), dim3(1024), 0, st, d.ctl, d.m, d.q, d.x, d.xbar, d.z,
-                       d.zbar, d.dx, d.dz, d.v, d.basis, d.nonbasis, d.var_col, d.binv, d.ldb,
-                       d.drow, d.dslot, d.U, d.ldw, d.W, d.ldw, d.plist, d.pslot, d.col0, d.col1,
-                       d.csc ? d.cptr : nullptr, d.log_kind,
-                       d.log_enter,
-                       d.log_leave, d.log_mu, d.log_margin, d.log_cap);
 }
 
 void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)

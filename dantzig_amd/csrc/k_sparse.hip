@@ -431,7 +431,7 @@ __device__ __forceinline__ int sp_pivot_books(
     ctl->sp_mcol = mcol;
     ctl->sp_zcol = zcol;
     ctl->ncompact = k;
-    // ---- swap, log, counters, list of nonbasic structural positions (as k_fast_pivot)
+    // ---- swap, log, counters, list of nonbasic structural positions (as fast_pivot_books of k_fast.hip)
     const long long it = c.iter;
     if (it < log_cap) {
         log_kind[it] = c.kind;
