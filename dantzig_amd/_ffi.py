@@ -36,7 +36,7 @@ EXPORTS = [
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
     "dzg_gen_dense_lp_block", "dzg_solver_set_profile", "dzg_kernel_neg_t_dot_csc",
-    "dzg_shard_comm_size",
+    "dzg_shard_comm_size", "dzg_solver_upload_columns",
 ]
 
 
@@ -57,7 +57,8 @@ class Opts(C.Structure):
         ("log_capacity", C.c_int64), ("poll_interval", C.c_int32), ("profile", C.c_int32),
         ("col_begin", C.c_int64), ("col_end", C.c_int64), ("rank", C.c_int32),
         ("world", C.c_int32), ("stream", C.c_void_p), ("refactor_interval", C.c_int64),
-        ("a_is_block", C.c_int32), ("near_tie_action", C.c_int32), ("tie_tol", C.c_double),
+        ("a_is_block", C.c_int32), ("near_tie_action", C.c_int32),
+        ("replicate_matrix", C.c_int32), ("reserved1", C.c_int32), ("tie_tol", C.c_double),
     ]
 
 
@@ -154,6 +155,8 @@ def lib() -> C.CDLL:
         _lib.dzg_solver_stream.argtypes = [C.c_void_p]
         _lib.dzg_solver_refactor.argtypes = [C.c_void_p]
         _lib.dzg_solver_set_profile.argtypes = [C.c_void_p, C.c_int32]
+        _lib.dzg_solver_upload_columns.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                   C.c_int64]
     return _lib
 
 

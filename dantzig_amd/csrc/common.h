@@ -342,7 +342,9 @@ struct DzgDev {
     double eps;
     // column sharding (world > 1): this rank holds structural columns [col0, col1)
     int col0, col1, rank, world;
-    long long xstride;   // exchange record stride in doubles
+    int repl;            // 1: every structural column is resident (A points at column col0 of the
+                         //    whole matrix, so `A + (code - col0) * lda` reaches any column)
+    long long xstride;   // exchange record stride in doubles (8: header only, repl)
 };
 
 #ifdef __HIPCC__
@@ -353,7 +355,8 @@ __device__ __forceinline__ const double *dzg_enter_col(const DzgCtl *ctl, int co
                                                        const double *xrecv, long long xstride)
 {
     if (code < 0) return nullptr;
-    if (xrecv) return xrecv + (long long)ctl->enter_src * xstride + 8;
+    // header-only records (xstride == 8): the matrix is replicated, every column is local
+    if (xrecv && xstride > 8) return xrecv + (long long)ctl->enter_src * xstride + 8;
     return A + (long long)(code - col0) * lda;
 }
 #endif

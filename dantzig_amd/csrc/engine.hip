@@ -102,6 +102,8 @@ struct dzg_solver {
     bool graphs_tried = false;
     int prof_slot = -1; // phase path: event slot of the iteration being enqueued (-1: none)
     int64_t refactors = 0;
+    double *A_alloc = nullptr;  // device matrix as allocated (d.A points at column col0 inside it)
+    long long cols_present = 0; // structural columns uploaded so far (replicate_matrix + a_is_block)
     double drift_trigger = 1e-9; // FAST health: disagreement of the two pivot elements that
                                  // triggers a refactorisation
     double max_err_life = 0.0; // largest ctl->max_pivot_err ever read (the device value restarts
@@ -225,6 +227,49 @@ extern "C" void dzg_solver_destroy(dzg_solver *s)
     delete s;
 }
 
+// columns [c0, c1) of the structural block into their slots of a replicated device matrix;
+// -0.0 entries become +0.0 like everywhere else (the reference's CSC drops exact zeros)
+static int upload_columns(dzg_solver *s, int64_t c0, int64_t c1, const double *a, int64_t lda)
+{
+    const DzgDev &d = s->d;
+    if (c1 <= c0 || d.m == 0) return 0;
+    const int64_t cnt = c1 - c0;
+    double *dst = s->A_alloc + (size_t)c0 * (size_t)d.lda;
+    bool has_negzero = false;
+    for (int64_t j = 0; j < cnt && !has_negzero; ++j)
+        for (int64_t i = 0; i < d.m; ++i) {
+            const double val = a[j * lda + i];
+            if (val == 0.0 && std::signbit(val)) { has_negzero = true; break; }
+        }
+    if (!has_negzero) {
+        HIP_OK(hipMemcpy2DAsync(dst, sizeof(double) * d.lda, a, sizeof(double) * lda,
+                                sizeof(double) * d.m, (size_t)cnt, hipMemcpyHostToDevice, s->st));
+    } else {
+        std::vector<double> tmp((size_t)d.m * (size_t)cnt);
+        for (int64_t j = 0; j < cnt; ++j)
+            for (int64_t i = 0; i < d.m; ++i) {
+                const double val = a[j * lda + i];
+                tmp[(size_t)(j * d.m + i)] = (val == 0.0) ? 0.0 : val;
+            }
+        HIP_OK(hipMemcpy2DAsync(dst, sizeof(double) * d.lda, tmp.data(), sizeof(double) * d.m,
+                                sizeof(double) * d.m, (size_t)cnt, hipMemcpyHostToDevice, s->st));
+    }
+    HIP_OK(hipStreamSynchronize(s->st)); // the caller may reuse its buffer
+    s->cols_present += cnt;
+    return 0;
+}
+
+extern "C" int dzg_solver_upload_columns(dzg_solver *s, int64_t col_begin, int64_t col_end,
+                                         const double *a, int64_t lda)
+{
+    if (!s || !a || !s->d.repl) return fail(DZG_E_ARG, "upload_columns: a solver with replicate_matrix");
+    if (col_begin < 0 || col_end > s->d.ns || col_begin > col_end || lda < s->d.m ||
+        (col_begin < s->d.col1 && col_end > s->d.col0))
+        return fail(DZG_E_ARG, "upload_columns: [col_begin, col_end) must lie outside the rank's own block");
+    HIP_OK(hipSetDevice(s->opts.device));
+    return upload_columns(s, col_begin, col_end, a, lda);
+}
+
 extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_solver **out)
 {
     if (!out) return fail(DZG_E_ARG, "out is NULL");
@@ -276,8 +321,10 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         d.col0 = (int)o.col_begin;
         d.col1 = (int)o.col_end;
     }
-    d.xstride = 8 + ((long long)m + 7) / 8 * 8;
-    const int nloc = d.col1 - d.col0; // structural columns resident on this device
+    const int nloc = d.col1 - d.col0; // structural columns this rank prices
+    // dense + replicate_matrix: all ns columns are resident, the exchange carries headers only
+    d.repl = (d.world > 1 && o.replicate_matrix && lp->a) ? 1 : 0;
+    d.xstride = d.repl ? 8 : 8 + ((long long)m + 7) / 8 * 8;
     const double *a_host = !lp->a ? nullptr
                            : (o.a_is_block && d.world > 1) ? lp->a
                                                            : lp->a + (size_t)d.col0 * (size_t)lp->lda;
@@ -342,8 +389,14 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     // --- constraint matrix: column-major, zero-padded to lda rows (16-B aligned columns)
     double *A = nullptr;
     const int ndense = d.csc ? 0 : nloc;
-    TRY(dev_alloc(s, &A, (size_t)d.lda * (size_t)(ndense ? ndense : 1)));
-    HIP_OK(hipMemsetAsync(A, 0, sizeof(double) * (size_t)d.lda * (size_t)(ndense ? ndense : 1), s->st));
+    const int nmem = d.csc ? 0 : (d.repl ? ns : nloc);       // columns held in HBM
+    const long long mem0 = d.repl ? 0 : d.col0;              // first of them
+    double *A_alloc = nullptr;
+    TRY(dev_alloc(s, &A_alloc, (size_t)d.lda * (size_t)(nmem ? nmem : 1)));
+    HIP_OK(hipMemsetAsync(A_alloc, 0, sizeof(double) * (size_t)d.lda * (size_t)(nmem ? nmem : 1), s->st));
+    A = A_alloc + (size_t)(d.col0 - mem0) * (size_t)d.lda;   // column col0: kernels index from it
+    s->A_alloc = A_alloc;
+    s->cols_present = d.repl ? nloc : ns;
     if (ndense > 0 && m > 0) {
         // the reference's CSC drops exact zeros (src/linalg.rs:261), so -0.0 entries act as +0.0
         bool has_negzero = false;
@@ -368,6 +421,12 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         }
     }
     d.A = A;
+    if (d.repl && !o.a_is_block && ns > nloc) {
+        // lp->a is the whole matrix: the other ranks' columns come from it right away
+        if (d.col0 > 0) TRY(upload_columns(s, 0, d.col0, lp->a, lp->lda));
+        if (d.col1 < ns)
+            TRY(upload_columns(s, d.col1, ns, lp->a + (size_t)d.col1 * (size_t)lp->lda, lp->lda));
+    }
 
     // --- index maps
     std::vector<int> var_col((size_t)(n ? n : 1));
@@ -444,9 +503,10 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         for (int p = 0; p < m; ++p)
             if (var_col[basis[p]] >= 0) slack_basis = false;
         if (!slack_basis) {
-            if (d.world > 1)
-                return fail(DZG_E_ARG, "a non-slack starting basis needs unsharded input in FAST "
-                                       "numerics");
+            if (d.world > 1 && !(d.repl && s->cols_present == ns))
+                return fail(DZG_E_ARG, "a non-slack starting basis of a column-sharded FAST solver "
+                                       "needs the whole matrix at creation (replicate_matrix, "
+                                       "a_is_block = 0)");
             if (o.refactor_interval == 0) o.refactor_interval = -1; // reserve the workspace
             s->opts.refactor_interval = o.refactor_interval;
         }
@@ -647,9 +707,9 @@ static int read_ctl(dzg_solver *s)
 static int refactor_workspace(dzg_solver *s)
 {
     if (s->rfG) return 0;
-    if (s->d.world > 1)
-        return fail(DZG_E_ARG, "refactorisation needs every basic column on the device: not "
-                               "available for a column-sharded solver");
+    if (s->d.world > 1 && !s->d.repl)
+        return fail(DZG_E_ARG, "refactorisation needs every basic column on the device: a "
+                               "column-sharded solver has them with opts.replicate_matrix only");
     const size_t m = (size_t)(s->d.m ? s->d.m : 1);
     s->rf_ld = ((long long)s->d.m + 15) / 16 * 16 + 16;
     double *g = nullptr;
@@ -716,6 +776,34 @@ static int health_stop(dzg_solver *s)
     return 0;
 }
 
+// FAST health between batches: the pivot element computed by FTRAN and by BTRAN + pricing must
+// agree.  A drift is shed by a refactorisation (workspace reserved on first need); where that is
+// impossible -- a partitioned sharded solver, out of memory -- or does not help, the solve stops
+// with DZG_SINGULAR.  Every rank of a sharded solve sees the same max_pivot_err (replicated dx_p,
+// published dz_r) and therefore takes the same action.
+static int health_check(dzg_solver *s, bool *stop)
+{
+    *stop = false;
+    const bool can_refactor = s->d.world == 1 || s->d.repl;
+    if (!can_refactor) {
+        TRY(health_stop(s));
+        *stop = s->h_ctl->status != DZG_RUNNING;
+        return 0;
+    }
+    if (s->h_ctl->max_pivot_err > s->drift_trigger && s->since_refactor > 0) {
+        // a basis whose fresh inverse drifts again at once is ill-conditioned, not stale:
+        // accept a larger disagreement instead of refactorising every batch
+        const bool fresh = s->refactors > 0 && s->since_refactor <= 2ll * s->opts.poll_interval;
+        if (fresh) s->drift_trigger *= 100.0;
+        if ((fresh && s->h_ctl->max_pivot_err > 1e-4) || refactor_now(s) != 0) {
+            s->h_ctl->max_pivot_err = 1.0;
+            TRY(health_stop(s));
+            *stop = true;
+        }
+    }
+    return 0;
+}
+
 // Budget spent: the host ends the run itself instead of enqueueing an iteration that would only
 // discover it (a no-op iteration would still advance the host's flush bookkeeping, and the eta
 // flush must fall after the same pivots however a solve is cut into runs: results are
@@ -764,20 +852,9 @@ static int run_fast(dzg_solver *s)
         HIP_OK(hipGetLastError());
         collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
-        // health: the pivot element computed by FTRAN and by BTRAN + pricing must agree.  A
-        // drift is shed by a refactorisation (workspace reserved on first need); only when that
-        // is impossible (out of memory) does the solve stop with DZG_SINGULAR.
-        if (s->h_ctl->max_pivot_err > s->drift_trigger && s->since_refactor > 0) {
-            // a basis whose fresh inverse drifts again at once is ill-conditioned, not stale:
-            // accept a larger disagreement instead of refactorising every batch
-            const bool fresh = s->refactors > 0 && s->since_refactor <= 2ll * s->opts.poll_interval;
-            if (fresh) s->drift_trigger *= 100.0;
-            if ((fresh && s->h_ctl->max_pivot_err > 1e-4) || refactor_now(s) != 0) {
-                s->h_ctl->max_pivot_err = 1.0;
-                TRY(health_stop(s));
-                break;
-            }
-        }
+        bool stop = false;
+        TRY(health_check(s, &stop));
+        if (stop) break;
     }
     return 0;
 }
@@ -846,6 +923,9 @@ static int run_strict(dzg_solver *s)
 
 static int set_budget(dzg_solver *s, int64_t max_new_iters)
 {
+    if (s->d.repl && s->cols_present != s->d.ns)
+        return fail(DZG_E_ARG, "replicate_matrix: " + std::to_string(s->d.ns - s->cols_present) +
+                               " structural columns have not been uploaded (dzg_solver_upload_columns)");
     TRY(read_ctl(s));
     DzgCtl *h = s->h_ctl;
     if (h->status != DZG_RUNNING && h->status != DZG_ITER_LIMIT && h->status != DZG_NEAR_TIE)
@@ -1022,9 +1102,12 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         bool spent = false;
         TRY(budget_spent(s, &spent));
         if (spent) break;
+        if (s->opts.refactor_interval > 0 && s->since_refactor >= s->opts.refactor_interval)
+            TRY(refactor_now(s));
         const long long before = s->h_ctl->iter;
         const int batch = batch_size(s);
         s->since_flush = s->h_ctl->neta;
+        s->since_refactor += batch;
         for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
@@ -1044,10 +1127,9 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         HIP_OK(hipGetLastError());
         collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
-        // max_pivot_err comes from the replicated dx_p and the published dz_r: it is the same
-        // on every rank, so all ranks stop together
-        TRY(health_stop(s));
-        if (s->h_ctl->status != DZG_RUNNING) break;
+        bool stop = false;
+        TRY(health_check(s, &stop));
+        if (stop) break;
     }
     s->solve_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return s->h_ctl->status;
@@ -1077,8 +1159,14 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         bool spent = false;
         for (int r = 0; r < world; ++r) TRY(budget_spent(sv[r], &spent));
         if (spent) break;
+        for (int r = 0; r < world; ++r)
+            if (sv[r]->opts.refactor_interval > 0 && sv[r]->since_refactor >= sv[r]->opts.refactor_interval)
+                TRY(refactor_now(sv[r]));
         const int batch = batch_size(sv[0]);
-        for (int r = 0; r < world; ++r) sv[r]->since_flush = sv[r]->h_ctl->neta;
+        for (int r = 0; r < world; ++r) {
+            sv[r]->since_flush = sv[r]->h_ctl->neta;
+            sv[r]->since_refactor += batch;
+        }
         for (int b = 0; b < batch; ++b) {
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));
             TRY(exchange(false));
@@ -1092,8 +1180,13 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
             if (sv[r]->h_ctl->status != sv[0]->h_ctl->status || sv[r]->h_ctl->iter != sv[0]->h_ctl->iter)
                 return fail(DZG_E_DEVICE, "lockstep: ranks diverged");
         if (sv[0]->h_ctl->status != DZG_RUNNING) break;
-        for (int r = 0; r < world; ++r) TRY(health_stop(sv[r]));
-        if (sv[0]->h_ctl->status != DZG_RUNNING) break;
+        bool stop = false;
+        for (int r = 0; r < world; ++r) {
+            bool one = false;
+            TRY(health_check(sv[r], &one));
+            stop = stop || one;
+        }
+        if (stop) break;
     }
     return sv[0]->h_ctl->status;
 }

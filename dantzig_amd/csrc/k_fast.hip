@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void k_shard_propose(
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dz,
     const double *__restrict__ pr, const int *__restrict__ pk, const double *__restrict__ ph,
-    int np, double *__restrict__ rec, int csc)
+    int np, double *__restrict__ rec, int csc, int hdr_only)
 {
     if (ctl->status != DZG_RUNNING) return;
     double ratio = 0.0, runner = -__builtin_inf();
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256) void k_shard_propose(
         }
         return;
     }
-    if (!want_column || code < 0) return;
+    if (!want_column || code < 0 || hdr_only) return;
     const int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
     // sparse matrix: zero the slot here, k_shard_scatter_col then drops the stored entries in
     if (i < m) rec[8 + i] = csc ? 0.0 : A[(long long)(code - col0) * lda + i];
@@ -936,15 +936,16 @@ void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
 
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st)
 {
-    const dim3 grid(1 + (d.m + 255) / 256);
+    const int hdr_only = d.xstride <= 8; // replicated matrix: the column is read locally
+    const dim3 grid(hdr_only ? 1 : 1 + (d.m + 255) / 256);
     if (mode == 0)
         hipLaunchKernelGGL((k_shard_propose<0>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
                            d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.fpz_r,
-                           d.fpz_k, d.fpz_h, DZG_NB_UPD, xsend, d.csc);
+                           d.fpz_k, d.fpz_h, DZG_NB_UPD, xsend, d.csc, hdr_only);
     else
         hipLaunchKernelGGL((k_shard_propose<1>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
                            d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.rz_r, d.rz_k,
-                           d.rz_h, nrz, xsend, d.csc);
+                           d.rz_h, nrz, xsend, d.csc, hdr_only);
     if (d.csc)
         hipLaunchKernelGGL(k_shard_scatter_col, dim3(1), dim3(256), 0, st, d.ctl, mode, d.cptr,
                            d.ridx, d.cval, d.col0, d.col1, xsend);

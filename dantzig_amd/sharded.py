@@ -36,13 +36,26 @@ def col_range(n_struct: int, rank: int, world: int) -> tuple[int, int]:
 class ShardedSolver(core.Solver):
     """One rank's share of a column-sharded solve."""
 
-    def __init__(self, lp: core.CoreLP, rank: int, world: int, stream: int = 0, **opts):
+    def __init__(self, lp: core.CoreLP, rank: int, world: int, stream: int = 0,
+                 replicate: bool = False, **opts):
+        """replicate=True (dense matrices): every rank keeps all structural columns in its HBM and
+        only the pricing is split, so the exchange records shrink to their headers and the solver
+        can refactorise.  A block LP (CoreLP.from_inequality_block) then takes the other ranks'
+        columns through upload_columns() before the first run."""
         begin, end = col_range(lp.n_struct, rank, world)
         self.rank, self.world = rank, world
         self.col_begin, self.col_end = begin, end
         super().__init__(lp, numerics=core.FAST, rank=rank, world=world, col_begin=begin,
-                         col_end=end, stream=stream or None, **opts)
+                         col_end=end, stream=stream or None,
+                         replicate_matrix=1 if (replicate and lp.a is not None) else 0, **opts)
         self.record_doubles = int(_ffi.lib().dzg_shard_record_doubles(self._h))
+
+    def upload_columns(self, begin: int, end: int, a_block) -> None:
+        """Columns [begin, end) of A (an (m, end - begin) array) of a replicated solver."""
+        a_cm = np.ascontiguousarray(np.asarray(a_block, dtype=np.float64).T)
+        rc = _ffi.lib().dzg_solver_upload_columns(self._h, int(begin), int(end), _ffi.ptr(a_cm),
+                                                  int(a_cm.shape[1]) if a_cm.ndim == 2 else 1)
+        _ffi.check(rc, "dzg_solver_upload_columns")
 
     @property
     def stream(self) -> int:
@@ -74,10 +87,10 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
-def make_lockstep(lp: core.CoreLP, world: int, **opts) -> list:
+def make_lockstep(lp: core.CoreLP, world: int, replicate: bool = False, **opts) -> list:
     """All ranks of a sharded solve inside ONE process on ONE GPU, sharing one stream."""
-    first = ShardedSolver(lp, 0, world, **opts)
-    return [first] + [ShardedSolver(lp, r, world, stream=first.stream, **opts)
+    first = ShardedSolver(lp, 0, world, replicate=replicate, **opts)
+    return [first] + [ShardedSolver(lp, r, world, stream=first.stream, replicate=replicate, **opts)
                       for r in range(1, world)]
 
 
@@ -104,10 +117,19 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
              "tree": core.PRICE_TREE}[price_name]
     # poll interval 50 divides the default warm-up and step counts: no partial batches
+    # The matrix fits one GPU many times over (config 5: 17 GB of 288): every rank keeps all of it
+    # and only the pricing is split, so the all-gathers carry 64-byte headers instead of columns.
+    # The other ranks' blocks are generated and uploaded one at a time (host peak: two blocks).
     solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price,
-                           profile=1 << _ffi.K_PRICE, poll_interval=50)
+                           profile=1 << _ffi.K_PRICE, poll_interval=50, replicate=True)
     try:
         del a, lp
+        for other in range(world):
+            if other != rank:
+                ob, oe = col_range(cols, other, world)
+                blk, _, _ = core.gen_dense_lp_block(seed, rows, cols, ob, oe)
+                solver.upload_columns(ob, oe, blk)
+                del blk
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
@@ -174,6 +196,7 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
             "numerics": "fast", "price_kernel": price_name,
             "status_after_timed_region": status, "requested_steps": steps,
             "exchanges_per_iteration": 2, "record_bytes": record_bytes,
+            "matrix": "replicated on every rank (pricing split by column block)",
             "collective": "ncclAllGather (RCCL) of one record per rank",
             "nranks_ncclCommCount": nranks,
             "lp_generation_s": round(t_gen, 3),

@@ -135,6 +135,15 @@ typedef struct {
                                  materialises the other ranks' part of the matrix; 0 = lp->a is
                                  the whole m x n_struct matrix and the block is taken from it   */
     int32_t near_tie_action;  /* FAST: dzg_near_tie_action, default COUNT                       */
+    int32_t replicate_matrix; /* column sharding, dense: 1 = every rank keeps ALL structural columns in
+                                 its HBM and only the PRICING is split by [col_begin, col_end): the
+                                 entering column is read locally, so the exchange records shrink to
+                                 their 64-byte headers, and a sharded solver can refactorise.  For
+                                 matrices that fit one GPU (config 5: 17 GB of 288).  With a_is_block
+                                 the other ranks' columns follow through dzg_solver_upload_columns.
+                                 0 = partitioned: a rank holds its block only, columns travel in
+                                 the records                                                     */
+    int32_t reserved1;
     double tie_tol;           /* FAST: a decision of the pivot rule is a "near tie" when winner and
                                  runner-up differ by less than max(tie_tol, 64 * max_pivot_error)
                                  relative, or rest on a denominator that is zero up to that
@@ -220,6 +229,11 @@ int dzg_solver_run(dzg_solver *s, int64_t max_new_iters);
 /* Copies state, pivot log and counters back to the host. */
 int dzg_solver_result(dzg_solver *s, dzg_result *res);
 void dzg_solver_destroy(dzg_solver *s);
+/* opts.replicate_matrix with opts.a_is_block: hands over the structural columns
+ * [col_begin, col_end) that the rank did not pass at creation (column col_begin first in `a`,
+ * leading dimension lda >= m).  Every column must be present before the first run. */
+int dzg_solver_upload_columns(dzg_solver *s, int64_t col_begin, int64_t col_end, const double *a,
+                              int64_t lda);
 /* FAST: rebuild the basis inverse from scratch now (needs opts.refactor_interval != 0 at
  * creation, which reserves the workspace). */
 int dzg_solver_refactor(dzg_solver *s);

@@ -270,3 +270,70 @@ def test_sharded_solve_is_bit_identical_to_the_unsharded_one(world):
         assert np.array_equal(res.x, single.x) and np.array_equal(res.xbar, single.xbar)
         assert res.objective == single.objective
         assert res.near_ties == single.near_ties and res.min_margin == single.min_margin
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_replicated_matrix_sharding_matches_oracle_and_single_gpu(world):
+    """opts.replicate_matrix: every rank holds all columns, only the pricing is split; the records
+    are 64-byte headers.  Same pivots as the oracle, same bits as the single-GPU solve -- and as
+    the partitioned sharding, whose records carry the columns."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+
+    a, b, c = core.gen_dense_lp(seed=39, m=160, n_struct=420)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    single = core.solve(lp, numerics=core.FAST, poll_interval=16)
+    solvers = make_lockstep(lp, world, replicate=True, poll_interval=16)
+    try:
+        assert all(s.record_doubles == 8 for s in solvers)
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == want.status == "optimal"
+    for res in results:
+        assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+        assert res.pivots == single.pivots and np.array_equal(res.x, single.x)
+        assert res.objective == single.objective
+
+
+@pytest.mark.gpu
+def test_replicated_sharding_from_column_blocks_and_refactorisation():
+    """Each rank is created with its own block only (a_is_block) and receives the other blocks
+    through dzg_solver_upload_columns; a run before that is refused.  With every column resident a
+    sharded solver can refactorise: a rebuild every 40 pivots leaves the pivot sequence alone."""
+    from dantzig_amd import _ffi, core
+    from dantzig_amd.sharded import ShardedSolver, col_range, run_lockstep
+
+    world, seed, m, ns = 3, 40, 96, 250
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    solvers = []
+    try:
+        for r in range(world):
+            begin, end = col_range(ns, r, world)
+            ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)
+            lp = core.CoreLP.from_inequality_block(ab, bb, cb, begin, end)
+            solvers.append(ShardedSolver(lp, r, world, poll_interval=8, replicate=True,
+                                         refactor_interval=40,
+                                         stream=solvers[0].stream if solvers else 0))
+        with pytest.raises(_ffi.DantzigAmdError, match="have not been uploaded"):
+            run_lockstep(solvers)
+        for r, s in enumerate(solvers):
+            for other in range(world):
+                if other != r:
+                    ob, oe = col_range(ns, other, world)
+                    s.upload_columns(ob, oe, np.asarray(a)[:, ob:oe])
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == want.status == "optimal"
+    for res in results:
+        assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+        assert res.refactors >= 2
+        assert abs(res.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
