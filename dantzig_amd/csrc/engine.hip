@@ -76,6 +76,7 @@ extern "C" void dzg_opts_default(dzg_opts *o)
     o->profile = 0;
     o->world = 1;
     o->near_tie_action = DZG_NEAR_TIE_COUNT;
+    o->auto_restart_rows = DZG_AUTO_STRICT_RESTART_ROWS;
     o->tie_tol = 1e-11;
 }
 
@@ -1307,7 +1308,8 @@ extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result
     // data), and the LP is solved again from the first pivot in the reference's own arithmetic;
     // the state vectors of a FAST run carry FAST's rounding, so no later point can be handed over
     // bit-exactly.  Above that size STRICT is out of reach and FAST reports what it met.
-    const bool can_restart = automatic && lp->m > strict_rows && lp->m <= DZG_AUTO_STRICT_RESTART_ROWS;
+    const int restart_rows = o.auto_restart_rows != 0 ? o.auto_restart_rows : DZG_AUTO_STRICT_RESTART_ROWS;
+    const bool can_restart = automatic && lp->m > strict_rows && lp->m <= restart_rows;
     if (can_restart && o.tie_tol >= 0.0) o.near_tie_action = DZG_NEAR_TIE_STOP;
     int rc = solve_once(lp, &o, res);
     if (rc < 0) return rc;

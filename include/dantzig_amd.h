@@ -143,7 +143,9 @@ typedef struct {
                                  the other ranks' columns follow through dzg_solver_upload_columns.
                                  0 = partitioned: a rank holds its block only, columns travel in
                                  the records                                                     */
-    int32_t reserved1;
+    int32_t auto_restart_rows; /* AUTO: largest LP (rows) that is re-solved in STRICT after FAST met a
+                                 near tie / lost its footing; default DZG_AUTO_STRICT_RESTART_ROWS
+                                 (2048: 57 ms per STRICT pivot); < 0: never re-solve            */
     double tie_tol;           /* FAST: a decision of the pivot rule is a "near tie" when winner and
                                  runner-up differ by less than max(tie_tol, 64 * max_pivot_error)
                                  relative, or rest on a denominator that is zero up to that
