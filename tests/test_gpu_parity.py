@@ -751,3 +751,34 @@ def test_refactor_workspace_is_reserved_on_first_need(core):
     assert res.refactors == 1                       # no refactorisation per batch afterwards
     assert res.max_pivot_error >= before.max_pivot_error   # the reported maximum is lifetime
     assert _log(res) == _log(want)
+
+
+def test_sparse_basis_with_dense_rows_reaches_the_highs_optimum(core):
+    """CSC input whose first two constraint rows are dense (every column has an entry there, as a
+    budget row of a user model would): once more than 1024 structurals are basic, the leaving-slack
+    BTRAN of those rows combines more rows of X than one LDS chunk holds (SP_LCAP) and the
+    basic-slack FTRAN walks lists of that length.  The whole FAST solve on the sparse-basis path
+    must reach the optimum an independent solver (scipy / HiGHS) finds, to 1e-9 relative."""
+    import scipy.sparse as sp
+    from scipy.optimize import linprog
+
+    rng = np.random.default_rng(77)
+    m, ns, per_col = 2200, 4000, 5
+    rows = np.concatenate([np.sort(rng.choice(np.arange(2, m), per_col, replace=False)) for _ in range(ns)])
+    cols = np.repeat(np.arange(ns), per_col)
+    vals = rng.uniform(-1, 1, ns * per_col)
+    a = sp.csc_matrix((vals, (rows, cols)), shape=(m, ns)).tolil()
+    a[0, :] = rng.uniform(0.1, 1.0, ns)          # two dense rows
+    a[1, :] = rng.uniform(-1.0, 1.0, ns)
+    a = sp.csc_matrix(a)
+    a.sort_indices()
+    x0, y0 = rng.uniform(0, 1, ns), rng.uniform(0, 1, m)
+    b = a @ x0 + rng.uniform(0, 1, m)            # x0 is feasible
+    c = a.T @ y0 - rng.uniform(0, 1, ns)         # y0 is dual feasible: bounded
+    lp = core.CoreLP.from_csc(m, a.indptr, a.indices, a.data, b, c)
+    res = core.solve(lp, log=False, numerics=core.FAST, poll_interval=128)
+    assert res.status == "optimal" and res.dense_columns > 1024
+    assert res.max_pivot_error < 1e-8
+    ref = linprog(-c, A_ub=a, b_ub=b, bounds=(0, None), method="highs")
+    assert ref.status == 0
+    assert abs(res.objective - (-ref.fun)) <= 1e-9 * max(1.0, abs(ref.fun))
