@@ -405,6 +405,8 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
                          int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
                          int *singular, hipStream_t st);
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
+void dzg_launch_lockstep_allgather(double *const *ptrs, int world, int which, long long xstride,
+                                   hipStream_t st);
 
 // k_sparse.hip
 void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st);

@@ -1147,13 +1147,21 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         if (rc0 != DZG_RUNNING) return rc0;
     }
     hipStream_t st = sv[0]->st;
-    const size_t nb = sizeof(double) * (size_t)sv[0]->d.xstride;
+    // the all-gather of the lockstep harness: ONE kernel copies every rank's record into every
+    // rank's receive buffer (world^2 device copies per exchange would cost more than the ranks'
+    // own kernels and blur the per-rank compute this harness is profiled for)
+    std::vector<double *> ptrs((size_t)3 * world);
+    for (int r = 0; r < world; ++r) {
+        ptrs[(size_t)r] = sv[r]->xsend;
+        ptrs[(size_t)world + r] = sv[r]->xrecv1;
+        ptrs[(size_t)2 * world + r] = sv[r]->xrecv2;
+    }
+    double **dptrs = nullptr;
+    HIP_OK(hipMalloc(&dptrs, sizeof(double *) * ptrs.size()));
+    struct Free { double **p; ~Free() { hipFree(p); } } free_ptrs{dptrs};
+    HIP_OK(hipMemcpy(dptrs, ptrs.data(), sizeof(double *) * ptrs.size(), hipMemcpyHostToDevice));
     auto exchange = [&](bool second) -> int {
-        for (int dst = 0; dst < world; ++dst)
-            for (int src = 0; src < world; ++src) {
-                double *to = (second ? sv[dst]->xrecv2 : sv[dst]->xrecv1) + (size_t)src * sv[0]->d.xstride;
-                HIP_OK(hipMemcpyAsync(to, sv[src]->xsend, nb, hipMemcpyDeviceToDevice, st));
-            }
+        dzg_launch_lockstep_allgather(dptrs, world, second ? 2 : 1, sv[0]->d.xstride, st);
         return 0;
     };
     for (;;) {

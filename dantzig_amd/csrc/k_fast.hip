@@ -950,3 +950,24 @@ void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend,
         hipLaunchKernelGGL(k_shard_scatter_col, dim3(1), dim3(256), 0, st, d.ctl, mode, d.cptr,
                            d.ridx, d.cval, d.col0, d.col1, xsend);
 }
+
+// Lockstep harness (all ranks in one process on one GPU): recv_dst[src] = send_src for every pair.
+// ptrs = [send_0..send_{P-1} | recv1_0.. | recv2_0..]; which = 1 or 2.  grid (blocks over a record, P*P)
+__global__ __launch_bounds__(256) void k_lockstep_allgather(double *const *ptrs, int world, int which,
+                                                            long long xstride)
+{
+    const int pair = blockIdx.y, dst = pair / world, src = pair % world;
+    const double *from = ptrs[src];
+    double *to = ptrs[(long long)which * world + dst] + (long long)src * xstride;
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < xstride; i += (long long)gridDim.x * blockDim.x)
+        to[i] = from[i];
+}
+
+void dzg_launch_lockstep_allgather(double *const *ptrs, int world, int which, long long xstride,
+                                   hipStream_t st)
+{
+    int bx = (int)((xstride + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_lockstep_allgather, dim3(bx, world * world), dim3(256), 0, st, ptrs, world,
+                       which, xstride);
+}
