@@ -199,14 +199,15 @@ def _pricing(r0, r1, kernel: str) -> dict:
 def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
     """The same solve deep into its trajectory: `late_pivots` pivots are skipped untimed (the
     basis inverse has grown to k dense columns by then, so FTRAN, the eta flush and the update
-    cost what they cost for most of a whole solve), then `steps` pivots are timed like the
-    primary region, then 256 more with every kernel class stamped for the per-class split."""
+    cost what they cost for most of a whole solve), then max(`steps`, 1000) pivots are timed like
+    the primary region, then 256 more with every kernel class stamped for the per-class split."""
     from dantzig_amd import _ffi
 
     skip = late_pivots - r1.iterations
     status = solver.run(skip) if skip > 0 else "iter_limit"
     if status != "iter_limit":
         return {"skipped": f"solve ended ({status}) before pivot {late_pivots}"}
+    steps = max(steps, 1000)  # a short --steps would time one poll batch: too noisy to compare
     ra = solver.result(log=False)
     t0 = time.perf_counter()
     status = solver.run(steps)
