@@ -41,6 +41,44 @@ __global__ __launch_bounds__(256) void k_persist(unsigned *counter, double *buf,
     if (threadIdx.x == 0 && bad) atomicAdd(errors, bad);
 }
 
+// The same exchange WITHOUT release/acquire fences: the published values travel as agent-scope
+// relaxed atomic stores / loads (sc1: past the XCD's L2, coherent at the memory side), the counter
+// is a relaxed atomic, and program order is kept with s_waitcnt.  An agent-scope release on this
+// chip writes back the whole L2 of the XCD (the eight L2s are not coherent with each other), which
+// is what the fenced barrier above pays for; data that is published explicitly does not need it.
+__device__ __forceinline__ void grid_barrier_relaxed(unsigned *counter, unsigned &gen)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gen += 1;
+        const unsigned target = gen * gridDim.x;
+        __builtin_amdgcn_s_waitcnt(0); // my sc1 stores have left
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+            __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_persist_relaxed(unsigned *counter, double *buf, int iters,
+                                                         int *errors)
+{
+    unsigned gen = 0;
+    const int nb = gridDim.x;
+    int bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&buf[blockIdx.x], (double)(it * 1000 + blockIdx.x), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        grid_barrier_relaxed(counter, gen);
+        const int other = (blockIdx.x + nb / 2 + 3) % nb;
+        const double got = __hip_atomic_load(&buf[other], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (got != (double)(it * 1000 + other)) bad++;
+        grid_barrier_relaxed(counter, gen);
+    }
+    if (threadIdx.x == 0 && bad) atomicAdd(errors, bad);
+}
+
 __global__ __launch_bounds__(256) void k_small(double *buf, int it)
 {
     if (threadIdx.x == 0) buf[blockIdx.x] = buf[(blockIdx.x + 7) % gridDim.x] + it;
@@ -69,6 +107,21 @@ int main()
         hipMemcpy(&herr, errors, 4, hipMemcpyDeviceToHost);
         printf("persistent kernel, %3d workgroups: %.2f us per grid barrier (%d stale reads)\n", blocks,
                std::chrono::duration<double, std::micro>(t1 - t0).count() / (2.0 * iters), herr);
+    }
+    for (int blocks : {64, 256, 512}) {
+        hipMemset(counter, 0, 4);
+        hipMemset(errors, 0, 4);
+        const int iters = 2000;
+        hipLaunchKernelGGL(k_persist_relaxed, dim3(blocks), dim3(256), 0, 0, counter, buf, 10, errors);
+        hipDeviceSynchronize();
+        hipMemset(counter, 0, 4);
+        auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_persist_relaxed, dim3(blocks), dim3(256), 0, 0, counter, buf, iters, errors);
+        hipDeviceSynchronize();
+        auto t1 = std::chrono::steady_clock::now();
+        hipMemcpy(&herr, errors, 4, hipMemcpyDeviceToHost);
+        printf("persistent kernel, %3d workgroups, NO fences (sc1 data, relaxed counter): %.2f us per grid barrier (%d stale reads)\n",
+               blocks, std::chrono::duration<double, std::micro>(t1 - t0).count() / (2.0 * iters), herr);
     }
     for (int blocks : {64, 256}) {
         const int iters = 4000;
