@@ -410,8 +410,7 @@ void dzg_launch_lockstep_allgather(double *const *ptrs, int world, int which, lo
 
 // k_sparse.hip
 void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st);
-void dzg_launch_sp_prep(const DzgDev &d, int mode, int nrz, hipStream_t st);
-void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, hipStream_t st);
+void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, int nrz, hipStream_t st);
 void dzg_launch_sp_btran(const DzgDev &d, hipStream_t st);
 void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st);
 void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st);

@@ -646,11 +646,8 @@ static void enqueue_sparse_iteration(dzg_solver *s, int slot)
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     Prof pf{s, slot};
-    pf.begin(DZG_K_STATUS);
-    dzg_launch_sp_prep(d, 0, 0, st);
-    pf.end(DZG_K_STATUS);
     pf.begin(DZG_K_FTRAN);
-    dzg_launch_sp_ftran(d, DZG_STEP_PRIMAL, st);
+    dzg_launch_sp_ftran(d, DZG_STEP_PRIMAL, 0, st); // status() + primal FTRAN (a no-op in a dual step)
     pf.end(DZG_K_FTRAN);
     pf.begin(DZG_K_BTRAN);
     dzg_launch_sp_btran(d, st);
@@ -659,8 +656,7 @@ static void enqueue_sparse_iteration(dzg_solver *s, int slot)
     dzg_launch_price_fast(d, price_kernel_for(s), st);
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_RATIO);
-    dzg_launch_sp_prep(d, 1, price_partials_for(s, price_kernel_for(s)), st);
-    dzg_launch_sp_ftran(d, DZG_STEP_DUAL, st);
+    dzg_launch_sp_ftran(d, DZG_STEP_DUAL, price_partials_for(s, price_kernel_for(s)), st); // ratio + dual FTRAN
     pf.end(DZG_K_RATIO);
     pf.begin(DZG_K_UPDATE);
     dzg_launch_sp_pivot(d, st);

@@ -68,7 +68,8 @@ __device__ __forceinline__ double ratio_margin(DzgCand2 c, double tau)
 // otherwise `kind` is the step and the control block holds kind, mu, enter_pos / leave_pos.
 __device__ __forceinline__ bool fast_status(DzgCtl *ctl, const DzgCtl &c, bool lead,
                                             const DzgCand2 &cj, const DzgCand2 &ci, double eps,
-                                            int m, bool from_records, int &kind_out)
+                                            int m, bool from_records, int &kind_out,
+                                            double *mu_out = nullptr)
 {
     const double inf = __builtin_inf();
     int kind = -1, verdict = DZG_RUNNING;
@@ -142,6 +143,7 @@ __device__ __forceinline__ bool fast_status(DzgCtl *ctl, const DzgCtl &c, bool l
         if (from_records) ctl->use_record = 0;
     }
     kind_out = kind;
+    if (mu_out) *mu_out = mu;
     return true;
 }
 

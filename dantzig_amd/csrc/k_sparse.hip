@@ -50,15 +50,21 @@ __device__ __forceinline__ double sp_block_sum(double x)
 }
 
 // ---------------------------------------------------------------------------------
-// k_sp_prep<MODE>: MODE 0 = status() at the head of the iteration, MODE 1 = the dual step's
-// ratio test after pricing (src/simplex.rs:274-306, :324-325); then the FTRAN preparation for the
-// entering variable: workgroup t < neta computes beta_t = W_t . a_R (a sparse dot), the last
-// workgroup swaps the dense copy of the entering column in `acol` (entries of the previous one
-// are cleared, so acol is zero outside the current column without an O(m) pass).
-// grid = R_ + 1 workgroups of 256.
+// k_sp_ftran_s<KIND>: the head of a step and dx on the structural basis positions.
+//   head (every workgroup, redundantly, from the same partial arrays: no preparation launch):
+//     KIND = PRIMAL  status() at the head of the iteration (src/simplex.rs:274-306); a dual step
+//                    ends the launch here;
+//     KIND = DUAL    the dual step's ratio test after pricing (:324-325);
+//     then the entering column's entries that lie in rows of R go through LDS and
+//     beta_t = W_t . a_R (a sparse dot, thread t) is formed; workgroup 0 also swaps the dense
+//     copy of the entering column in `acol` (the previous column's entries are cleared, so acol
+//     is zero outside the current column without an O(m) pass) and publishes the decision.
+//   body: dx_S[b] = sum_e X[b][slot_e] a_e - sum_t Ub[t][b] beta_t, one thread per row b of X.
+// A primal step leaves per-workgroup ratio-test candidates (src/simplex.rs:439-461).
+// grid = min(ceil(m / 256), SP_NB) workgroups of 256 (k <= m is only known on the device).
 // ---------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void k_sp_prep(
+template <int KIND>
+__global__ __launch_bounds__(256) void k_sp_ftran_s(
     DzgCtl *ctl, int m, const long long *__restrict__ cptr, const int *__restrict__ ridx,
     const double *__restrict__ cval, const int *__restrict__ nonbasis,
     const int *__restrict__ var_col, const double *__restrict__ fpx_r,
@@ -66,46 +72,44 @@ __global__ __launch_bounds__(256) void k_sp_prep(
     const double *__restrict__ fpz_r, const int *__restrict__ fpz_k,
     const double *__restrict__ fpz_h, const double *__restrict__ rz_r,
     const int *__restrict__ rz_k, const double *__restrict__ rz_h, int nrz,
+    const double *__restrict__ X, long long ldb, const double *__restrict__ U, long long ldu,
     const double *__restrict__ W, long long ldw, const int *__restrict__ dslot,
-    double *__restrict__ beta, double *__restrict__ acol, int *acol_code, double eps)
+    const int *__restrict__ spos, const double *__restrict__ x, const double *__restrict__ xbar,
+    double *__restrict__ dxs, double *__restrict__ dx, double *__restrict__ rx_r,
+    int *__restrict__ rx_k, double *__restrict__ rx_h, double *__restrict__ acol, int *acol_code,
+    double eps)
 {
+    __shared__ int s_slot[256];
+    __shared__ double s_val[256];
+    __shared__ double s_beta[R_];
     const DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    // ---- head: every workgroup takes the decision itself (the control block may already carry
+    // the lead's version of it: only fields no decision writes are read from the snapshot)
     int epos;
-    if (MODE == 0) {
+    double mu;
+    if (KIND == DZG_STEP_PRIMAL) {
         const DzgCand2 cj = reduce_partials(fpz_r, fpz_k, fpz_h, SP_NB_UPD);
         const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, SP_NB_UPD);
         int kind;
-        if (!fast_status(ctl, c, lead, cj, ci, eps, m, false, kind)) return;
+        if (!fast_status(ctl, c, lead, cj, ci, eps, m, false, kind, &mu)) return;
         if (kind != DZG_STEP_PRIMAL) return;
         epos = cj.k;
     } else {
-        if (c.kind != DZG_STEP_DUAL) return;
+        if (c.kind != DZG_STEP_DUAL) return; // (written by the primal launch of this iteration)
         const DzgCand2 cw = reduce_partials(rz_r, rz_k, rz_h, nrz);
         if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_INFEASIBLE)) return;
         epos = cw.k;
+        mu = c.mu;
         if (lead) ctl->enter_pos = epos;
     }
     const int code = var_col[nonbasis[epos]];
     if (lead) ctl->enter_code = code;
-    const int b = blockIdx.x;
-    if (b < R_) {
-        if (b >= c.neta) return;
-        const double *wt = W + (long long)b * ldw;
-        if (code < 0) {
-            const int slot = dslot[-1 - code];
-            if (threadIdx.x == 0) beta[b] = slot >= 0 ? wt[slot] : 0.0;
-            return;
-        }
-        double acc = 0.0;
-        for (long long e = cptr[code] + threadIdx.x; e < cptr[code + 1]; e += blockDim.x) {
-            const int slot = dslot[ridx[e]];
-            if (slot >= 0) acc = fma(wt[slot], cval[e], acc);
-        }
-        acc = sp_block_sum(acc);
-        if (threadIdx.x == 0) beta[b] = acc;
-    } else {
+    const int k = c.ncompact, neta = c.neta;
+    const double tau = c.tau;
+    const long long e0 = code >= 0 ? cptr[code] : 0, e1 = code >= 0 ? cptr[code + 1] : 1;
+    if (blockIdx.x == 0) { // the dense copy of the entering column, for k_sp_ftran_l
         const int prev = *acol_code; // INT_MIN: nothing scattered yet
         if (prev != (int)0x80000000) {
             if (prev < 0) {
@@ -119,51 +123,47 @@ __global__ __launch_bounds__(256) void k_sp_prep(
         if (code < 0) {
             if (threadIdx.x == 0) acol[-1 - code] = 1.0;
         } else {
-            for (long long e = cptr[code] + threadIdx.x; e < cptr[code + 1]; e += blockDim.x)
-                acol[ridx[e]] = cval[e];
+            for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) acol[ridx[e]] = cval[e];
         }
         if (threadIdx.x == 0) *acol_code = code;
     }
-}
-
-// ---------------------------------------------------------------------------------
-// k_sp_ftran_s: dx on the structural basis positions, dx_S[b] = sum_e X[b][slot_e] a_e
-// - sum_t Ub[t][b] beta_t, one thread per row b of X; the entries of a_R are staged through LDS.
-// A primal step leaves per-workgroup ratio-test candidates (src/simplex.rs:439-461).
-// grid = min(ceil(m / 256), SP_NB) workgroups of 256 (k <= m is only known on the device).
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sp_ftran_s(
-    const DzgCtl *ctl, int need_kind, const long long *__restrict__ cptr,
-    const int *__restrict__ ridx, const double *__restrict__ cval,
-    const double *__restrict__ X, long long ldb, const double *__restrict__ U, long long ldu,
-    const double *__restrict__ beta, const int *__restrict__ dslot,
-    const int *__restrict__ spos, const double *__restrict__ x, const double *__restrict__ xbar,
-    double *__restrict__ dxs, double *__restrict__ dx, double *__restrict__ rx_r,
-    int *__restrict__ rx_k, double *__restrict__ rx_h)
-{
-    __shared__ int s_slot[256];
-    __shared__ double s_val[256];
-    __shared__ double s_beta[R_];
-    const DzgCtl c = *ctl;
-    if (c.status != DZG_RUNNING || c.kind != need_kind) return;
-    const int k = c.ncompact, neta = c.neta, code = c.enter_code;
-    const double mu = c.mu, tau = c.tau;
-    if (threadIdx.x < R_) s_beta[threadIdx.x] = threadIdx.x < neta ? beta[threadIdx.x] : 0.0;
+    // ---- beta_t = W_t . a_R, thread t, over the column's entries in chunks of 256
+    double bacc = 0.0;
+    for (long long base = e0; base < e1; base += 256) {
+        __syncthreads();
+        const long long e = base + threadIdx.x;
+        if (e < e1) {
+            const int r = code >= 0 ? ridx[e] : -1 - code;
+            s_slot[threadIdx.x] = dslot[r];
+            s_val[threadIdx.x] = code >= 0 ? cval[e] : 1.0;
+        }
+        __syncthreads();
+        const int cnt = (int)((e1 - base) < 256 ? (e1 - base) : 256);
+        if ((int)threadIdx.x < neta) {
+            const double *wt = W + (long long)threadIdx.x * ldw;
+            for (int i = 0; i < cnt; ++i)
+                if (s_slot[i] >= 0) bacc = fma(wt[s_slot[i]], s_val[i], bacc);
+        }
+    }
+    if (threadIdx.x < R_) s_beta[threadIdx.x] = (int)threadIdx.x < neta ? bacc : 0.0;
+    // ---- body (the last chunk of the column is still staged when there is only one)
     DzgCand2 best = dzg_cand2_none();
-    const long long e0 = code >= 0 ? cptr[code] : 0, e1 = code >= 0 ? cptr[code + 1] : 1;
+    const bool one_chunk = e1 - e0 <= 256;
     for (int b0 = blockIdx.x * blockDim.x; b0 < k; b0 += gridDim.x * blockDim.x) { // block-uniform
         const int b = b0 + threadIdx.x;
         const double *row = X + (long long)(b < k ? b : 0) * ldb;
         double acc = 0.0;
         for (long long base = e0; base < e1; base += 256) {
-            __syncthreads();
-            const long long e = base + threadIdx.x;
-            if (e < e1) {
-                const int r = code >= 0 ? ridx[e] : -1 - code;
-                s_slot[threadIdx.x] = dslot[r];
-                s_val[threadIdx.x] = code >= 0 ? cval[e] : 1.0;
+            if (!one_chunk) {
+                __syncthreads();
+                const long long e = base + threadIdx.x;
+                if (e < e1) {
+                    const int r = code >= 0 ? ridx[e] : -1 - code;
+                    s_slot[threadIdx.x] = dslot[r];
+                    s_val[threadIdx.x] = code >= 0 ? cval[e] : 1.0;
+                }
             }
-            __syncthreads();
+            __syncthreads(); // (also orders s_beta before its first use)
             const int cnt = (int)((e1 - base) < 256 ? (e1 - base) : 256);
             if (b < k)
                 for (int i = 0; i < cnt; ++i)
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
             const int i = spos[b];
             dxs[b] = acc;
             dx[i] = acc;
-            if (need_kind == DZG_STEP_PRIMAL) {
+            if (KIND == DZG_STEP_PRIMAL) {
                 const double xi = x[i], scaled = mu * xbar[i];
                 const double den = xi + scaled;
                 DzgCand2 cnd;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
             }
         }
     }
-    if (need_kind == DZG_STEP_PRIMAL) {
+    if (KIND == DZG_STEP_PRIMAL) {
         best = dzg_block_best2(best);
         if (threadIdx.x == 0) {
             rx_r[blockIdx.x] = best.r;
@@ -783,24 +783,21 @@ void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st)
                        d.bslot, d.bcnt, d.bcol, d.bval);
 }
 
-void dzg_launch_sp_prep(const DzgDev &d, int mode, int nrz, hipStream_t st)
-{
-#define SP_PREP_ARGS d.ctl, d.m, d.cptr, d.ridx, d.cval, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k,     \
-                     d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.rz_r, d.rz_k, d.rz_h, nrz, d.W, d.ldw,     \
-                     d.dslot, d.beta, d.acol, d.acol_code, d.eps
-    if (mode == 0)
-        hipLaunchKernelGGL((k_sp_prep<0>), dim3(R_ + 1), dim3(256), 0, st, SP_PREP_ARGS);
-    else
-        hipLaunchKernelGGL((k_sp_prep<1>), dim3(R_ + 1), dim3(256), 0, st, SP_PREP_ARGS);
-#undef SP_PREP_ARGS
-}
-
-void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, hipStream_t st)
+// need_kind = PRIMAL: the head of the iteration (status + primal FTRAN); DUAL: after pricing
+// (ratio test with `nrz` pricing partials + dual FTRAN).  Two launches each: structural
+// positions (with the head), then the positions of the basic slacks.
+void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, int nrz, hipStream_t st)
 {
     const int gs = sp_grid(d.m), gl = sp_grid(d.m);
-    hipLaunchKernelGGL(k_sp_ftran_s, dim3(gs), dim3(256), 0, st, d.ctl, need_kind, d.cptr, d.ridx,
-                       d.cval, d.binv, d.ldb, d.U, d.ldw, d.beta, d.dslot, d.spos, d.x, d.xbar, d.dxs,
-                       d.dx, d.rx_r, d.rx_k, d.rx_h);
+#define SP_FS_ARGS d.ctl, d.m, d.cptr, d.ridx, d.cval, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k, d.fpx_h,  \
+                   d.fpz_r, d.fpz_k, d.fpz_h, d.rz_r, d.rz_k, d.rz_h, nrz, d.binv, d.ldb, d.U, d.ldw, d.W,  \
+                   d.ldw, d.dslot, d.spos, d.x, d.xbar, d.dxs, d.dx, d.rx_r, d.rx_k, d.rx_h, d.acol,        \
+                   d.acol_code, d.eps
+    if (need_kind == DZG_STEP_PRIMAL)
+        hipLaunchKernelGGL((k_sp_ftran_s<DZG_STEP_PRIMAL>), dim3(gs), dim3(256), 0, st, SP_FS_ARGS);
+    else
+        hipLaunchKernelGGL((k_sp_ftran_s<DZG_STEP_DUAL>), dim3(gs), dim3(256), 0, st, SP_FS_ARGS);
+#undef SP_FS_ARGS
     hipLaunchKernelGGL(k_sp_ftran_l, dim3(gl), dim3(256), 0, st, d.ctl, need_kind, d.m, d.rptr,
                        d.bcnt, d.bcol, d.bval, d.bslot, d.rowpos, d.acol, d.dxs, d.x, d.xbar, d.dx,
                        d.rx_r, d.rx_k, d.rx_h, gs);
