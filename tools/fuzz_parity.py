@@ -9,7 +9,10 @@ outcomes under the reference's one-sided status() quirk) and 0/1 data.
           pivot) must equal the oracle in status and pivot log: "another verdict" must be 0.
 
   python3 tools/fuzz_parity.py [cases] [first_seed] [max rows (70)] [iteration cap (20000)]
-                               [min rows (1)] [families, e.g. 12 = integer + 0/1 only]
+                               [min rows (1)] [families, e.g. 12 = integer + 0/1 only] [csc]
+
+With a trailing `csc` the same LPs are handed over as CSC (zeros dropped, like the reference's
+CscMatrix): FAST then runs on the sparse-basis path (k_sparse.hip), STRICT on its CSC gathers.
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,6 +40,7 @@ if __name__ == "__main__":
     cap = int(sys.argv[4]) if len(sys.argv) > 4 else 20000
     min_m = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     families = [int(ch) for ch in sys.argv[6]] if len(sys.argv) > 6 else [0, 1, 2]
+    as_csc = "csc" in sys.argv[7:]
     bad_strict, bad_auto, unflagged, flagged_div, statuses = [], [], [], [], {}
     false_pos = {0: 0, 1: 0, 2: 0}
     clean = {0: 0, 1: 0, 2: 0}
@@ -50,7 +54,14 @@ if __name__ == "__main__":
         per_kind[kind] += 1
         want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=cap)
         statuses[want.status] = statuses.get(want.status, 0) + 1
-        lp = core.CoreLP.from_inequality_form(a, b, c)
+        if as_csc:
+            import scipy.sparse as sp
+            acsc = sp.csc_matrix(a)
+            acsc.eliminate_zeros()
+            acsc.sort_indices()
+            lp = core.CoreLP.from_csc(m, acsc.indptr, acsc.indices, acsc.data, b, c)
+        else:
+            lp = core.CoreLP.from_inequality_form(a, b, c)
         wlog = log3(want.pivots)
         s = core.solve(lp, numerics=core.STRICT, max_iter=cap)
         ok = (s.status == want.status and log3(s.pivots) == wlog
@@ -86,7 +97,7 @@ if __name__ == "__main__":
             print(f"  {case + 1} cases, {time.time() - t0:.0f} s; STRICT mismatches {len(bad_strict)}, "
                   f"FAST divergences flagged {len(flagged_div)} / UNFLAGGED {len(unflagged)}, "
                   f"AUTO mismatches {len(bad_auto)}", flush=True)
-    print(f"{cases} cases from seed {seed0}, rows {min_m}..{max_m - 1}, families {families} "
+    print(f"{cases} cases from seed {seed0}{' (CSC input)' if as_csc else ''}, rows {min_m}..{max_m - 1}, families {families} "
           f"(0 continuous G1, 1 small integers, 2 zero/one): oracle outcomes {statuses}")
     print("STRICT mismatches (seed, kind, m, ns, got, want):", bad_strict)
     print(f"FAST (near ties counted): per family cases {per_kind}; followed the oracle unflagged "
