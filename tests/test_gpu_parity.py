@@ -782,3 +782,38 @@ def test_sparse_basis_with_dense_rows_reaches_the_highs_optimum(core):
     ref = linprog(-c, A_ub=a, b_ub=b, bounds=(0, None), method="highs")
     assert ref.status == 0
     assert abs(res.objective - (-ref.fun)) <= 1e-9 * max(1.0, abs(ref.fun))
+
+
+def test_sparse_basis_path_leaves_the_oracle_path_only_where_it_flagged_a_near_tie(core):
+    """The three LP families handed over as CSC (FAST runs on the sparse-basis path, k_sparse.hip:
+    rows and columns of X appended, deleted and recycled, per-row lists of basic entries): 120 small
+    LPs; continuous data follows the oracle with nothing flagged, any divergence on integer / 0-1
+    data was flagged at or before the differing pivot, and AUTO equals the oracle throughout."""
+    import scipy.sparse as sp
+
+    from tests.lp_families import log3, make_lp
+
+    unflagged, bad_auto, bad_continuous = [], [], []
+    for seed in range(7300, 7420):
+        kind = seed % 3
+        a, b, c = make_lp(seed, kind, 2, 50)
+        want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=5000)
+        acsc = sp.csc_matrix(a)
+        acsc.eliminate_zeros()
+        acsc.sort_indices()
+        lp = core.CoreLP.from_csc(a.shape[0], acsc.indptr, acsc.indices, acsc.data, b, c)
+        f = core.solve(lp, numerics=core.FAST, max_iter=5000, poll_interval=8)
+        got, wlog = log3(f.pivots), log3(want.pivots)
+        if kind == 0 and (f.near_ties or got != wlog or f.status != want.status):
+            bad_continuous.append((seed, f.near_ties, f.status, want.status))
+        if got != wlog or f.status != want.status:
+            d = next((i for i, (p, q) in enumerate(zip(got, wlog)) if p != q),
+                     min(len(got), len(wlog)))
+            if not 0 <= f.first_near_tie <= d:
+                unflagged.append((seed, kind, f.status, want.status, d, f.first_near_tie))
+        r = core.core_solve(lp, numerics=core.AUTO, max_iter=5000, auto_strict_rows=1, log_cap=5000)
+        if r.status != want.status or log3(r.pivots) != wlog:
+            bad_auto.append((seed, kind, r.status, want.status, r.numerics))
+    assert not unflagged, unflagged
+    assert not bad_continuous, bad_continuous
+    assert not bad_auto, bad_auto
