@@ -225,15 +225,25 @@ def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
         solver.run(256)
         rc = solver.result(log=False)
         n = max(rc.iterations - rb.iterations, 1)
-        names = {"status": "status + primal FTRAN prep", "ftran": "FTRAN GEMV (primal)",
-                 "btran": "BTRAN row", "price": "pricing", "ratio": "dual ratio + prep + FTRAN GEMV",
-                 "update": "pivot + update", "basis_update": "eta flush (amortised)"}
+        if rc.kernel_launches["status"] > rb.kernel_launches["status"]:
+            names = {"status": "status + primal FTRAN prep", "ftran": "FTRAN GEMV (primal)",
+                     "btran": "BTRAN row", "price": "pricing",
+                     "ratio": "dual ratio + prep + FTRAN GEMV", "update": "pivot + update",
+                     "basis_update": "eta flush (amortised)"}
+        else:  # the three-launch chain (csrc/k_chain.hip)
+            names = {"ftran": "k_chain_pre: status, primal FTRAN + ratio test, BTRAN row",
+                     "price": "pricing",
+                     "update": "k_chain_post: dual ratio test + FTRAN, pivot's books, update",
+                     "basis_update": "eta flush (amortised)"}
         out["kernel_us_per_pivot"] = {
             label: round(1e3 * (rc.kernel_ms[k] - rb.kernel_ms[k]) / n, 2)
             for k, label in names.items()}
         out["kernel_us_note"] = (f"HIP events around each kernel class over {n} further pivots "
                                  "(event overhead included; not part of any reported rate)")
     return out
+
+
+SEVEN_LAUNCHES = False  # --seven-launches: the FAST iteration as seven kernels instead of three
 
 
 def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, warmup,
@@ -258,7 +268,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
         "k_price_seq2" if numerics_name == "strict" else PRICE_KERNELS[price_name])
     t_up = time.perf_counter()
     solver = core.Solver(lp, numerics=numerics, price_kernel=price,
-                         profile=1 << _ffi.K_PRICE, poll_interval=50)
+                         profile=1 << _ffi.K_PRICE, poll_interval=50,
+                         seven_launches=1 if SEVEN_LAUNCHES else 0)
     t_up = time.perf_counter() - t_up
     late = None
     try:
@@ -296,6 +307,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                          f"nonzeros per column (CSC), generator G2 seed {seed}"),
             "numerics": r1.numerics,
             "price_kernel": price_name,
+            "launches_per_iteration": (8 if sparse_per_col > 0 else 7 if SEVEN_LAUNCHES else 3)
+            if numerics_name == "fast" else None,
             "status_after_timed_region": status,
             "requested_steps": steps,
             "k_at_start": r0.dense_columns,
@@ -329,6 +342,9 @@ def main() -> int:
                     help="skip the second timed region deep in the solve (the \"late\" block)")
     ap.add_argument("--late-pivots", type=int, default=20000,
                     help="pivots skipped untimed before the late region (default 20000, ~4 s)")
+    ap.add_argument("--seven-launches", action="store_true",
+                    help="FAST, dense, one GPU: run an iteration as the seven launches a sharded "
+                         "solver uses instead of the three-launch chain (same pivots)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the 32768x65536 measurement that rides along with the default run")
     ap.add_argument("--sparse-per-col", type=int, default=0,
@@ -372,6 +388,8 @@ def main() -> int:
     # its stream, which brackets the timed region the way torch.cuda.synchronize() would.
     _ffi.require_gpu()
     late_pivots = 0 if (args.no_late or under_profiler()) else args.late_pivots
+    global SEVEN_LAUNCHES
+    SEVEN_LAUNCHES = bool(args.seven_launches)
     out = measure(args.rows, args.cols, args.seed, args.sparse_per_col, args.price, args.numerics,
                   args.steps, args.warmup, late_pivots)
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None

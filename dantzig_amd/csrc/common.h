@@ -66,7 +66,16 @@ struct DzgCtl {
     // workgroups may still be reading neta / ncompact: the new values wait here until
     // k_fast_update (the next launch) commits them
     int neta_next, ncompact_next;
+    int fp_count;         // first-pivot partials per side the last update left (its grid size)
+    // three-launch chain (k_chain.hip).  k_chain_pre leaves here what k_chain_post's workgroups
+    // need about the pivot rows / columns: inside that launch they must not read anything the
+    // pivot's books (one workgroup of the same launch) or another workgroup's update rewrites
+    int leave_code;       // column code of the leaving variable
+    int enter_dslot;      // compact column of the entering slack's row (entering slack only)
+    int neta_cur, k_cur;  // neta and ncompact of the iteration in flight
     int pad3;
+    double xp, xbp;       // x, xbar at the leaving position
+    unsigned long long bar_gen; // device-wide barriers passed so far (k_chain.hip)
 };
 
 // Partial-reduction fan-in sizes of the FAST pipeline (fixed grids => fixed counts)
@@ -407,6 +416,13 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
 void dzg_launch_lockstep_allgather(double *const *ptrs, int world, int which, long long xstride,
                                    hipStream_t st);
+
+// k_chain.hip: the FAST iteration of the dense inverse in three launches (one GPU)
+#define DZG_CHAIN_AGCAP 16384 // compact width up to which the chain runs (the gathered column in LDS)
+void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
+                          unsigned long long *dbg, hipStream_t st);
+void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
+                           unsigned long long *dbg, int only_partials, int nrz, hipStream_t st);
 
 // k_sparse.hip
 void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st);

@@ -109,6 +109,13 @@ struct dzg_solver {
                                  // triggers a refactorisation
     double max_err_life = 0.0; // largest ctl->max_pivot_err ever read (the device value restarts
                                // at every refactorisation)
+    // FAST, dense, one GPU: the three-launch chain (k_chain.hip)
+    unsigned long long *chain_bar = nullptr; // barrier counters (never reset)
+    unsigned long long *chain_dbg = nullptr; // DZG_CHAIN_DEBUG=1: phase clocks of workgroup 0
+    int chain_grid = 0;                      // one workgroup per CU
+    long long chain_kcap = DZG_CHAIN_AGCAP;  // compact width beyond which a batch runs as seven
+                                             // launches (DZG_CHAIN_KCAP lowers it: tests)
+    bool batch_chain = false;                // the batch in flight runs the chain
     // column sharding
     void *comm = nullptr;                  // ncclComm_t
     double *xsend = nullptr, *xrecv1 = nullptr, *xrecv2 = nullptr;
@@ -215,9 +222,32 @@ static int shard_buffers(dzg_solver *s);
 static int refactor_now(dzg_solver *s);
 static int refactor_workspace(dzg_solver *s);
 
+// DZG_CHAIN_DEBUG=1: where workgroup 0 of the chain kernels spent its time (stderr, at destroy)
+static void chain_debug_report(dzg_solver *s)
+{
+    unsigned long long h[64];
+    if (hipMemcpy(h, s->chain_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    static const char *names[4] = {"k_chain_pre  primal", "k_chain_pre  dual  ", "k_chain_post primal",
+                                   "k_chain_post dual  "};
+    for (int slot = 0; slot < 4; ++slot) {
+        const double n = (double)h[16 * slot + 15];
+        if (n <= 0) continue;
+        std::fprintf(stderr, "[chain] %s x%-8.0f us per stage:", names[slot], n);
+        double tot = 0;
+        for (int st = 0; st < 15; ++st) {
+            if (!h[16 * slot + st]) continue;
+            const double us = (double)h[16 * slot + st] / n / 100.0; // 100 MHz clock
+            tot += us;
+            std::fprintf(stderr, " %d:%.2f", st, us);
+        }
+        std::fprintf(stderr, "  sum %.2f\n", tot);
+    }
+}
+
 extern "C" void dzg_solver_destroy(dzg_solver *s)
 {
     if (!s) return;
+    if (s->chain_dbg) chain_debug_report(s);
     shard_comm_destroy(s);
     for (hipGraphExec_t g : s->g_solve)
         if (g) hipGraphExecDestroy(g);
@@ -538,6 +568,25 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             HIP_OK(hipMemsetAsync(d.acol, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
             HIP_OK(hipMemsetAsync(d.dxs, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
         }
+        if (d.world == 1 && !d.csc && !o.seven_launches) {
+            // the chain's barriers need every workgroup resident at once: one per CU
+            hipDeviceProp_t prop;
+            HIP_OK(hipGetDeviceProperties(&prop, o.device));
+            s->chain_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+            if (s->chain_grid > 1024) s->chain_grid = 1024;
+            if (const char *cap = std::getenv("DZG_CHAIN_KCAP")) {
+                const long long v = std::atoll(cap);
+                if (v >= 0 && v < s->chain_kcap) s->chain_kcap = v;
+            }
+            if (const char *dbg = std::getenv("DZG_CHAIN_DEBUG")) {
+                if (dbg[0] == '1') {
+                    TRY(dev_alloc(s, &s->chain_dbg, (size_t)64));
+                    HIP_OK(hipMemsetAsync(s->chain_dbg, 0, sizeof(unsigned long long) * 64, s->st));
+                }
+            }
+            TRY(dev_alloc(s, &s->chain_bar, (size_t)16 * 9));
+            HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * 16 * 9, s->st));
+        }
         dzg_launch_fast_init(d, s->st);
         if (d.spb) {
             dzg_launch_sp_init(d, 1, s->st);
@@ -640,6 +689,30 @@ static void enqueue_fast_iteration(dzg_solver *s, int slot)
     }
 }
 
+// Dense matrix on one GPU: the same iteration in three launches (k_chain.hip).
+static void enqueue_chain_iteration(dzg_solver *s, int slot)
+{
+    const DzgDev &d = s->d;
+    hipStream_t st = s->st;
+    Prof pf{s, slot};
+    const int pk = price_kernel_for(s);
+    pf.begin(DZG_K_FTRAN);
+    dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, st); // status, primal FTRAN + ratio, BTRAN row
+    pf.end(DZG_K_FTRAN);
+    pf.begin(DZG_K_PRICE);
+    dzg_launch_price_fast(d, pk, st);
+    pf.end(DZG_K_PRICE);
+    pf.begin(DZG_K_UPDATE);
+    dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0, price_partials_for(s, pk), st);
+    pf.end(DZG_K_UPDATE);
+    pf.begin(DZG_K_BASIS_UPDATE);
+    if (++s->since_flush >= DZG_RMAX) {
+        dzg_launch_fast_flush(d, st);
+        s->since_flush = 0;
+    }
+    pf.end(DZG_K_BASIS_UPDATE);
+}
+
 // CSC input on one GPU: the sparse-basis kernels (k_sparse.hip).  Same phases as above.
 static void enqueue_sparse_iteration(dzg_solver *s, int slot)
 {
@@ -678,6 +751,8 @@ static void collect_profile(dzg_solver *s, int slots_real)
             if (!(s->opts.profile & (1 << cls))) continue;
             if (s->d.csc && !s->d.spb && s->d.world == 1 && !s->comm && cls != DZG_K_PRICE)
                 continue; // the single-GPU record path of a CSC solver only stamps pricing
+            if (s->batch_chain && (cls == DZG_K_STATUS || cls == DZG_K_BTRAN || cls == DZG_K_RATIO))
+                continue; // the chain has no launches of their own for these
             float ms = 0.f;
             size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
             if (hipEventElapsedTime(&ms, s->ev[base], s->ev[base + 1]) == hipSuccess) {
@@ -842,7 +917,13 @@ static int run_fast(dzg_solver *s)
             }
             s->prof_slot = -1;
         } else {
-            for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
+            // the chain keeps the gathered entering column in LDS: beyond that compact width
+            // (k grows by at most one per pivot) the batch runs as seven launches
+            s->batch_chain = s->chain_bar && (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
+            if (s->batch_chain)
+                for (int b = 0; b < batch; ++b) enqueue_chain_iteration(s, b);
+            else
+                for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
         }
         s->since_refactor += batch;
         TRY(read_ctl(s));

@@ -25,8 +25,11 @@ __device__ __forceinline__ DzgCand2 reduce_partials(const double *__restrict__ p
 // the run BEFORE the pivot with DZG_NEAR_TIE (every workgroup takes the same decision from the
 // same data, so all return together); count mode records it and carries on.  `first` marks the
 // first decision site of an iteration, which opens the per-pivot record.
+// `c` is the caller's snapshot of the control block; what the lead lane writes to the control
+// block is applied to it too, so a kernel that takes several decisions in a row (k_chain.hip)
+// carries the record on without reading the control block again.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ bool tie_gate(DzgCtl *ctl, const DzgCtl &c, bool lead, double margin,
+__device__ __forceinline__ bool tie_gate(DzgCtl *ctl, DzgCtl &c, bool lead, double margin,
                                          bool first)
 {
     const bool inside = !(margin > c.tau);
@@ -34,10 +37,14 @@ __device__ __forceinline__ bool tie_gate(DzgCtl *ctl, const DzgCtl &c, bool lead
         if (lead) ctl->status = DZG_NEAR_TIE;
         return true;
     }
+    const double new_margin = first ? margin : (margin < c.margin ? margin : c.margin);
+    const int new_seen = (first ? 0 : c.tie_seen) | (inside ? 1 : 0);
     if (lead) {
-        ctl->margin = first ? margin : (margin < c.margin ? margin : c.margin);
-        ctl->tie_seen = (first ? 0 : c.tie_seen) | (inside ? 1 : 0);
+        ctl->margin = new_margin;
+        ctl->tie_seen = new_seen;
     }
+    c.margin = new_margin;
+    c.tie_seen = new_seen;
     return false;
 }
 
@@ -66,7 +73,7 @@ __device__ __forceinline__ double ratio_margin(DzgCand2 c, double tau)
 // status() on the two first-pivot winners cj (z side) and ci (x side).  Returns false when the
 // calling kernel has nothing more to do (terminated, stopped at a near tie, budget spent);
 // otherwise `kind` is the step and the control block holds kind, mu, enter_pos / leave_pos.
-__device__ __forceinline__ bool fast_status(DzgCtl *ctl, const DzgCtl &c, bool lead,
+__device__ __forceinline__ bool fast_status(DzgCtl *ctl, DzgCtl &c, bool lead,
                                             const DzgCand2 &cj, const DzgCand2 &ci, double eps,
                                             int m, bool from_records, int &kind_out,
                                             double *mu_out = nullptr)
@@ -142,6 +149,10 @@ __device__ __forceinline__ bool fast_status(DzgCtl *ctl, const DzgCtl &c, bool l
         ctl->leave_pos = kind == DZG_STEP_DUAL ? ci.k : -1;
         if (from_records) ctl->use_record = 0;
     }
+    c.kind = kind;
+    c.mu = mu;
+    c.enter_pos = kind == DZG_STEP_PRIMAL ? cj.k : -1;
+    c.leave_pos = kind == DZG_STEP_DUAL ? ci.k : -1;
     kind_out = kind;
     if (mu_out) *mu_out = mu;
     return true;
@@ -149,7 +160,7 @@ __device__ __forceinline__ bool fast_status(DzgCtl *ctl, const DzgCtl &c, bool l
 
 // Outcome of a ratio test whose block partials reduced to `cw`: near-tie gate, then `none_status`
 // (DZG_UNBOUNDED in a primal step, DZG_INFEASIBLE in a dual step) when no candidate survived.
-__device__ __forceinline__ bool fast_ratio_outcome(DzgCtl *ctl, const DzgCtl &c, bool lead,
+__device__ __forceinline__ bool fast_ratio_outcome(DzgCtl *ctl, DzgCtl &c, bool lead,
                                                    const DzgCand2 &cw, int none_status)
 {
     const double margin = ratio_margin(cw, c.tau);

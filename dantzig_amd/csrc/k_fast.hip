@@ -31,24 +31,7 @@
 // ties), workgroup 0 publishes the decision in the control block for the next kernel.
 #include "common.h"
 #include "fast_decide.h"
-
-typedef double double2_t __attribute__((ext_vector_type(2)));
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-#define R_ DZG_RMAX
-
-__device__ __forceinline__ double block_sum(double x)
-{
-    __shared__ double s_sum[16];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, DZG_WAVE);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    double t = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_sum[w];
-    return t;
-}
+#include "fast_rows.h"
 
 // Merge of the ranks' proposals.  Slack positions are replicated, so several ranks may propose
 // the SAME position (with the same ratio): that is one candidate, not a tie.
@@ -111,8 +94,8 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         if (MODE == 4)
             w = shard_merge(xrecv, xstride, world, cj);
         else
-            cj = reduce_partials(fpz_r, fpz_k, fpz_h, DZG_NB_UPD);
-        const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, DZG_NB_UPD);
+            cj = reduce_partials(fpz_r, fpz_k, fpz_h, c.fp_count);
+        const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, c.fp_count);
         int kind;
         if (!fast_status(ctl, c, lead, cj, ci, eps, m, MODE == 4, kind)) return;
         if (kind != DZG_STEP_PRIMAL) return;
@@ -189,16 +172,7 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
             if (threadIdx.x == 0) beta[b] = wt[-1 - code];
             return;
         }
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int i = threadIdx.x;
-        for (; i + 3 * 256 < m; i += 4 * 256) { // four loads in flight per array and thread
-            a0 = fma(wt[i], a[i], a0);
-            a1 = fma(wt[i + 256], a[i + 256], a1);
-            a2 = fma(wt[i + 512], a[i + 512], a2);
-            a3 = fma(wt[i + 768], a[i + 768], a3);
-        }
-        for (; i < m; i += 256) a0 = fma(wt[i], a[i], a0);
-        double acc = block_sum((a0 + a1) + (a2 + a3));
+        const double acc = fast_beta_dot(wt, a, m);
         if (threadIdx.x == 0) beta[b] = acc;
     } else {
         if (code < 0) {
@@ -210,184 +184,6 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         // pad to a multiple of 2 so the GEMV can read 16 B at a time
         if (threadIdx.x == 0 && (k & 1)) ag[k] = 0.0;
     }
-}
-
-// ---------------------------------------------------------------------------------
-// fast_pivot_books: step lengths and the finiteness assert (src/simplex.rs:257-260,:464-468), swap
-// (:239-251), pivot log, then the basis bookkeeping: eta append, compact column append /
-// delete, list of nonbasic structural positions.  Work for ONE workgroup; it has no kernel of its
-// own: it runs in the dual-step launch of k_fast_gemv, which precedes the update kernel in every
-// iteration -- as workgroup 0 in a primal step (that launch has nothing else to do then: dx, dz,
-// p and r are all known), as the LAST workgroup to finish its rows of dx in a dual step.
-// `c` is the control block as that kernel found it.
-// ---------------------------------------------------------------------------------
-struct DzgPivotArgs {
-    int m, q;
-    const double *x, *xbar, *z, *zbar, *dx, *dz, *v;
-    int *basis, *nonbasis;
-    const int *var_col;
-    double *binv;
-    long long ldb;
-    int *drow, *dslot;
-    double *W;
-    long long ldw;
-    int *plist, *pslot;
-    int col0, col1;
-    const long long *cptr;
-    int *log_kind, *log_enter, *log_leave;
-    double *log_mu, *log_margin;
-    long long log_cap;
-};
-
-__device__ __forceinline__ void fast_pivot_books(DzgCtl *ctl, const DzgCtl &c, const DzgPivotArgs &pa,
-                                                 double dxp)
-{
-    __shared__ int s_ok, s_k, s_ci, s_cj;
-    const int m = pa.m, q = pa.q, col0 = pa.col0, col1 = pa.col1;
-    const double *x = pa.x, *xbar = pa.xbar, *z = pa.z, *zbar = pa.zbar, *dz = pa.dz;
-    int *basis = pa.basis, *nonbasis = pa.nonbasis, *drow = pa.drow, *dslot = pa.dslot;
-    int *plist = pa.plist, *pslot = pa.pslot;
-    const int *var_col = pa.var_col;
-    double *binv = pa.binv, *W = pa.W;
-    const long long ldb = pa.ldb, ldw = pa.ldw, log_cap = pa.log_cap;
-    const long long *cptr = pa.cptr;
-    int *log_kind = pa.log_kind, *log_enter = pa.log_enter, *log_leave = pa.log_leave;
-    double *log_mu = pa.log_mu, *log_margin = pa.log_margin;
-    const int tid = threadIdx.x;
-    const int p = c.leave_pos, r = c.enter_pos, neta = c.neta;
-    const bool rec = c.use_record != 0;
-    const long long s0 = c.nb_struct;
-    // hop 2: everything addressed by p, r -- issued together, used below
-    int vi = 0, vj = 0, idx_r = 0, lastpos = 0;
-    double max_err = c.max_pivot_err;
-    if (tid == 0) {
-        vi = basis[p];
-        vj = nonbasis[r];
-        const double xp = x[p], xbp = xbar[p]; // (dx_p comes from the workgroup's own GEMV row)
-        const double zr = rec ? c.zr : z[r], zbr = rec ? c.zbar_r : zbar[r];
-        const double dzr = rec ? c.dz_r : dz[r];
-        idx_r = pslot[r];
-        lastpos = s0 > 0 ? plist[s0 - 1] : 0;
-        // hop 3: the two column codes
-        const int ci = var_col[vi], cj = var_col[vj];
-        int ok = 1;
-        const double t = dzg_safe_divide(xp, dxp, &ok);
-        const double s = dzg_safe_divide(zr, dzr, &ok);
-        const double tbar = dzg_safe_divide(xbp, dxp, &ok);
-        const double sbar = dzg_safe_divide(zbr, dzr, &ok);
-        if (neta >= R_) ok = 0; // the host flushes every DZG_RMAX pivots; never reached
-        // the pivot element is known twice: dx_p = (B^-1 a_j)_p from FTRAN and -dz_r = v . a_j
-        // from BTRAN + pricing.  Their disagreement measures what the explicit inverse lost.
-        {
-            const double a1 = fabs(dxp), a2 = fabs(dzr);
-            const double den = a1 > a2 ? a1 : a2;
-            const double err = den > 0.0 ? fabs(dxp + dzr) / den : 0.0;
-            if (err > max_err) max_err = err;
-        }
-        if (ok) {
-            ctl->t = t;
-            ctl->s = s;
-            ctl->tbar = tbar;
-            ctl->sbar = sbar;
-        } else {
-            ctl->status = DZG_PANIC; // assert in safe_divide, src/simplex.rs:466
-        }
-        s_ok = ok;
-        s_k = c.ncompact;
-        s_ci = ci;
-        s_cj = cj;
-    }
-    __syncthreads();
-    if (!s_ok) return;
-    const int ci = s_ci, cj = s_cj;
-    // (the eta of this pivot, u = (dx - e_p)/dx_p and w = v, is appended by k_fast_update,
-    // which runs on the whole chip: here one workgroup only keeps the books)
-    // ---- a leaving slack makes the column of its row dense: it was e_p
-    if (ci < 0 && tid == 0) {
-        const int k = s_k, rl = -1 - ci;
-        drow[k] = rl;
-        dslot[rl] = k;
-        binv[(long long)p * ldb + k] = 1.0; // columns >= ncompact are kept zero
-        s_k = k + 1;
-    }
-    // ---- an entering slack makes the column of its row the unit vector e_p again: its compact
-    // column is deleted (swap with the last).  The books are kept here; the m-row column move
-    // itself is done by k_fast_update on the whole chip (ctl->del_ce / del_last).
-    int del_ce = -1, del_last = -1;
-    if (cj < 0) {
-        const int re = -1 - cj;
-        for (int t = tid; t < neta; t += blockDim.x) W[(long long)t * ldw + re] = 0.0;
-        if (tid == 0) {
-            const int ce = dslot[re], last = s_k - 1;
-            if (ce != last) {
-                const int lr = drow[last];
-                drow[ce] = lr;
-                dslot[lr] = ce;
-            }
-            dslot[re] = -1;
-            s_k = last;
-            del_ce = ce;
-            del_last = last;
-        }
-    }
-    if (tid != 0) return;
-    // ---- swap, log, counters (single lane)
-    const long long it = c.iter;
-    if (it < log_cap) {
-        log_kind[it] = c.kind;
-        log_enter[it] = vj;
-        log_leave[it] = vi;
-        log_mu[it] = c.mu;
-    }
-    long long s = s0;
-    // algorithmic bytes of this iteration's pricing pass; sparse: 12 B per stored
-    // entry of the nonbasic structural columns + their column pointers
-    double bytes = c.price_bytes;
-    if (cptr)
-        bytes += 12.0 * (double)c.nb_nnz + 4.0 * (double)(s + 1) + 8.0 * (double)m + 32.0 * (double)q;
-    else
-        bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
-    ctl->price_bytes = bytes;
-    basis[p] = vj;
-    nonbasis[r] = vi;
-    // nonbasic position r now holds vi instead of vj; the list only tracks OWNED columns
-    const bool own_j = cj >= col0 && cj < col1, own_i = ci >= col0 && ci < col1;
-    if (cptr) {
-        long long nnz = c.nb_nnz;
-        if (own_j) nnz -= cptr[cj - col0 + 1] - cptr[cj - col0];
-        if (own_i) nnz += cptr[ci - col0 + 1] - cptr[ci - col0];
-        ctl->nb_nnz = nnz;
-    }
-    if (own_j && !own_i) { // an owned structural column left the nonbasic set
-        plist[idx_r] = lastpos;
-        pslot[lastpos] = idx_r;
-        pslot[r] = -1;
-        --s;
-    } else if (!own_j && own_i) {
-        plist[s] = r;
-        pslot[r] = (int)s;
-        ++s;
-    }
-    ctl->nb_struct = s;
-    ctl->enter_var = vj;
-    ctl->leave_var = vi;
-    ctl->ncompact_next = s_k; // committed by k_fast_update: this launch still reads the old ones
-    ctl->del_ce = del_ce;
-    ctl->del_last = del_last;
-    ctl->neta_next = neta + 1;
-    ctl->max_pivot_err = max_err;
-    // near-tie record of this pivot; the tolerance follows the health monitor
-    if (it < log_cap) log_margin[it] = c.margin;
-    if (c.margin < c.min_margin) ctl->min_margin = c.margin;
-    if (c.tie_seen) {
-        ctl->near_ties = c.near_ties + 1;
-        if (c.first_near_tie < 0) ctl->first_near_tie = it;
-    }
-    if (c.tie_tol >= 0.0) {
-        const double adaptive = 64.0 * max_err;
-        ctl->tau = adaptive > c.tie_tol ? adaptive : c.tie_tol;
-    }
-    ctl->iter = it + 1;
 }
 
 // ---------------------------------------------------------------------------------
@@ -419,38 +215,9 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
     const double mu = ctl->mu, tau = ctl->tau;
     for (int i0 = wave_global * RPW; i0 < m; i0 += nwaves * RPW) {
         const int i = i0 + grp;
-        double acc = 0.0;
-        if (i < m) {
-            const double *row = binv + (long long)i * ldb;
-            double a0 = 0.0, a1 = 0.0;
-            int c = 2 * sub;
-            for (; c + 2 * LPR < k2; c += 4 * LPR) {
-                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-                const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 2 * LPR);
-                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
-                const double2_t g1 = *reinterpret_cast<const double2_t *>(ag + c + 2 * LPR);
-                a0 = fma(r0.x, g0.x, a0);
-                a1 = fma(r1.x, g1.x, a1);
-                a0 = fma(r0.y, g0.y, a0);
-                a1 = fma(r1.y, g1.y, a1);
-            }
-            for (; c < k2; c += 2 * LPR) {
-                const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-                const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
-                a0 = fma(r0.x, g0.x, a0);
-                a0 = fma(r0.y, g0.y, a0);
-            }
-            acc = a0 + a1;
-            for (int t = sub; t < neta; t += LPR) acc = fma(-U[(long long)t * ldu + i], beta[t], acc);
-        }
-#pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+        double acc = fast_gemv_row<LPR>(i, m, k2, neta, binv, ldb, ag, U, ldu, beta, sub);
         if (i < m && sub == 0) {
-            const int bc = var_col[basis[i]];
-            if (bc < 0) { // position i holds the slack of row rr: unit column contributes a_j[rr]
-                const int rr = -1 - bc;
-                acc += code >= 0 ? acolp[rr] : ((-1 - code) == rr ? 1.0 : 0.0);
-            }
+            acc = fast_gemv_unit(acc, var_col[basis[i]], code, acolp);
             dx[i] = acc;
             if (i == want_row) *want_dx = acc; // (LDS: the row whose dx the pivot's books need)
             if (need_kind == DZG_STEP_PRIMAL) {
@@ -531,7 +298,7 @@ __global__ __launch_bounds__(256) void k_fast_btran(
     const double *__restrict__ rx_h, double *__restrict__ v)
 {
     __shared__ double s_up[R_];
-    const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
+    DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
     int p;
     if (c.kind == DZG_STEP_PRIMAL) {
@@ -595,6 +362,7 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
         ctl->neta = c.neta_next;
         ctl->ncompact = c.ncompact_next;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fp_count = (int)gridDim.x;
     const int teta = neta_new - 1;
     const int wzero = c.enter_code < 0 ? -1 - c.enter_code : -1;
     const double rdxp = only_partials ? 0.0 : 1.0 / dx[p];
@@ -891,15 +659,7 @@ void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const doubl
 // keeps the books of the pivot (fast_pivot_books), whatever the step kind.
 void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, hipStream_t st)
 {
-    DzgPivotArgs pa;
-    pa.m = d.m; pa.q = d.q;
-    pa.x = d.x; pa.xbar = d.xbar; pa.z = d.z; pa.zbar = d.zbar; pa.dx = d.dx; pa.dz = d.dz; pa.v = d.v;
-    pa.basis = d.basis; pa.nonbasis = d.nonbasis; pa.var_col = d.var_col;
-    pa.binv = d.binv; pa.ldb = d.ldb; pa.drow = d.drow; pa.dslot = d.dslot;
-    pa.W = d.W; pa.ldw = d.ldw; pa.plist = d.plist; pa.pslot = d.pslot;
-    pa.col0 = d.col0; pa.col1 = d.col1; pa.cptr = d.csc ? d.cptr : nullptr;
-    pa.log_kind = d.log_kind; pa.log_enter = d.log_enter; pa.log_leave = d.log_leave;
-    pa.log_mu = d.log_mu; pa.log_margin = d.log_margin; pa.log_cap = d.log_cap;
+    const DzgPivotArgs pa = dzg_pivot_args(d);
 #define GEMV_ARGS d.ctl, need_kind, d.m, d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.col0, xrecv,  \
                   d.xstride, d.basis, d.nonbasis, d.var_col, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h, pa
     if (need_kind == DZG_STEP_DUAL)

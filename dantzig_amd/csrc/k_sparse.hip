@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
     __shared__ int s_slot[256];
     __shared__ double s_val[256];
     __shared__ double s_beta[R_];
-    const DzgCtl c = *ctl;
+    DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     // ---- head: every workgroup takes the decision itself (the control block may already carry
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     __shared__ double s_coef[SP_LCAP];
     __shared__ double s_gamma[R_];
     __shared__ int s_cnt;
-    const DzgCtl c = *ctl;
+    DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     int p;
     if (c.kind == DZG_STEP_PRIMAL) {

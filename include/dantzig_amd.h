@@ -150,6 +150,11 @@ typedef struct {
                                  runner-up differ by less than max(tie_tol, 64 * max_pivot_error)
                                  relative, or rest on a denominator that is zero up to that
                                  tolerance.  Default 1e-11; < 0 switches the detector off       */
+    int32_t seven_launches;   /* FAST, dense matrix, one GPU: 0 (default) = an iteration is three
+                                 launches (k_chain_pre, pricing, k_chain_post: device-wide barriers
+                                 inside, csrc/k_chain.hip); 1 = the seven launches a column-sharded
+                                 solver runs between its exchanges.  Same arithmetic, same pivots. */
+    int32_t reserved0;
 } dzg_opts;
 
 /* What FAST numerics does at a near tie (the pivot rule is a first-wins strict argmax,

@@ -817,3 +817,79 @@ def test_sparse_basis_path_leaves_the_oracle_path_only_where_it_flagged_a_near_t
     assert not unflagged, unflagged
     assert not bad_continuous, bad_continuous
     assert not bad_auto, bad_auto
+
+
+# ------------------------------------------------------------------ three launches == seven launches
+def _same_solution(r, w):
+    return (r.status == w.status and r.iterations == w.iterations and r.pivots == w.pivots
+            and r.near_ties == w.near_ties and r.first_near_tie == w.first_near_tie
+            and all(_same_bits(getattr(r, f), getattr(w, f)) for f in ("x", "xbar", "z", "zbar"))
+            and _same_bits(r.margins, w.margins) and r.max_pivot_error == w.max_pivot_error)
+
+
+def test_chain_and_seven_launches_are_the_same_solve(core):
+    """FAST on one GPU runs an iteration as three launches with device-wide barriers inside
+    (csrc/k_chain.hip); column-sharded solvers (and opts.seven_launches) run it as seven.  Same row,
+    dot-product and book-keeping functions: pivot log, mu, margins, monitor and the four vectors are
+    bit-identical -- on continuous data and on the integer / 0-1 families, whose pivots append and
+    delete compact columns (slack leaves, slack enters, both at once) and end unbounded,
+    infeasible, optimal or at the iteration cap."""
+    from tests.lp_families import make_lp
+
+    bad, statuses = [], {}
+    for seed in range(9100, 9190):
+        a, b, c = make_lp(seed, seed % 3, 2, 90)
+        lp = core.CoreLP.from_inequality_form(a, b, c)
+        r3 = core.solve(lp, numerics=core.FAST, max_iter=3000, poll_interval=16)
+        r7 = core.solve(lp, numerics=core.FAST, max_iter=3000, poll_interval=16, seven_launches=1)
+        statuses[r3.status] = statuses.get(r3.status, 0) + 1
+        if not _same_solution(r3, r7):
+            bad.append((seed, a.shape, r3.status, r7.status, r3.iterations, r7.iterations))
+    assert not bad, bad
+    assert len(statuses) >= 3, statuses
+
+
+def test_chain_follows_the_oracle_and_survives_stops_and_refactorisations(core):
+    """The chain under everything a run can be cut by: budgets that end between its launches'
+    iterations, near-tie stops (resumed), a refactorisation every 50 pivots -- against the
+    oracle's pivot log on a continuous LP of 300 rows (eta flushes every 64 pivots, several
+    thousand pivots)."""
+    from tests.lp_families import log3
+
+    m, ns = 300, 600
+    a, b, c = core.gen_dense_lp(seed=9201, m=m, n_struct=ns)
+    want = ora.simplex_solve(ora.stdform_from_dense(np.array(a), b, c), max_iter=200000)
+    wlog = log3(want.pivots)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    with core.Solver(lp, numerics=core.FAST, poll_interval=7, refactor_interval=50,
+                     near_tie_action=core.NEAR_TIE_STOP) as s:
+        status, runs = "iter_limit", 0
+        while status in ("iter_limit", "near_tie"):
+            status = s.run(37)
+            runs += 1
+            assert runs < 100000
+        r = s.result()
+    assert status == want.status == r.status
+    assert log3(r.pivots) == wlog
+    assert r.refactors >= len(wlog) // 100
+    assert abs(r.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+
+
+def test_chain_hands_over_to_seven_launches_when_the_inverse_outgrows_lds(core, monkeypatch):
+    """The chain keeps the gathered entering column in LDS (16 384 doubles); a batch that could
+    outgrow it runs as seven launches instead.  With the cap lowered to 24 columns the two forms
+    alternate within one solve (k rises and falls around the cap): still the seven-launch solve
+    bit for bit, and the oracle's pivot log."""
+    from tests.lp_families import log3
+
+    a, b, c = core.gen_dense_lp(seed=9301, m=120, n_struct=260)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    r7 = core.solve(lp, numerics=core.FAST, poll_interval=5, seven_launches=1)
+    monkeypatch.setenv("DZG_CHAIN_KCAP", "24")
+    rmix = core.solve(lp, numerics=core.FAST, poll_interval=5)
+    monkeypatch.delenv("DZG_CHAIN_KCAP")
+    r3 = core.solve(lp, numerics=core.FAST, poll_interval=5)
+    assert _same_solution(rmix, r7) and _same_solution(r3, r7)
+    assert r7.dense_columns > 24  # the cap was crossed
+    want = ora.simplex_solve(ora.stdform_from_dense(np.array(a), b, c), max_iter=100000)
+    assert log3(r3.pivots) == log3(want.pivots) and r3.status == want.status
