@@ -330,6 +330,8 @@ struct DzgDev {
     int *fpx_k, *fpz_k, *rx_k, *rz_k;    // partial candidates (positions)
     double *fpx_h, *fpz_h, *rx_h, *rz_h; // partial candidates (runner-up ratios, DzgCand2::h)
     double *log_margin;                  // [log_cap] smallest decision margin of each pivot
+    int *bcode, *nbcode;                 // [m], [q] column code of the variable at each basis /
+                                         // nonbasis position (var_col[basis[p]]: one load, not two)
     // sparse-basis mode (spb != 0: CSC input on one GPU, k_sparse.hip): binv holds X = the k x k
     // block of B^-1 (row b = structural basis position spos[b], column c = constraint row drow[c]),
     // U and W the pending etas in the same compact numbering

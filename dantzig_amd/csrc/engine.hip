@@ -553,6 +553,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.Wc, (size_t)d.ldw * DZG_RMAX));
         TRY(dev_alloc(s, &d.ag, (size_t)m + 2)); TRY(dev_alloc(s, &d.beta, (size_t)DZG_RMAX));
         TRY(dev_alloc(s, &d.plist, (size_t)q)); TRY(dev_alloc(s, &d.pslot, (size_t)q));
+        TRY(dev_alloc(s, &d.bcode, (size_t)m)); TRY(dev_alloc(s, &d.nbcode, (size_t)q));
         const size_t np = 4096;
         TRY(dev_alloc(s, &d.fpx_r, np)); TRY(dev_alloc(s, &d.fpz_r, np));
         TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));
@@ -572,20 +573,26 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             // the chain's barriers need every workgroup resident at once: one per CU
             hipDeviceProp_t prop;
             HIP_OK(hipGetDeviceProperties(&prop, o.device));
-            s->chain_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-            if (s->chain_grid > 1024) s->chain_grid = 1024;
-            if (const char *cap = std::getenv("DZG_CHAIN_KCAP")) {
-                const long long v = std::atoll(cap);
-                if (v >= 0 && v < s->chain_kcap) s->chain_kcap = v;
-            }
-            if (const char *dbg = std::getenv("DZG_CHAIN_DEBUG")) {
-                if (dbg[0] == '1') {
-                    TRY(dev_alloc(s, &s->chain_dbg, (size_t)64));
-                    HIP_OK(hipMemsetAsync(s->chain_dbg, 0, sizeof(unsigned long long) * 64, s->st));
+            int grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+            if (grid > 256) grid = 256; // (k_chain_pre reads <= 256 candidates)
+            // a thread takes one row and one column of its workgroup's share (512 threads)
+            const long long rows_per = (((long long)m + grid - 1) / grid + 3) & ~3ll;
+            const long long cols_per = ((long long)q + grid - 1) / grid;
+            if (rows_per <= 512 && cols_per <= 512) {
+                s->chain_grid = grid;
+                if (const char *cap = std::getenv("DZG_CHAIN_KCAP")) {
+                    const long long v = std::atoll(cap);
+                    if (v >= 0 && v < s->chain_kcap) s->chain_kcap = v;
                 }
+                if (const char *dbg = std::getenv("DZG_CHAIN_DEBUG")) {
+                    if (dbg[0] == '1') {
+                        TRY(dev_alloc(s, &s->chain_dbg, (size_t)64));
+                        HIP_OK(hipMemsetAsync(s->chain_dbg, 0, sizeof(unsigned long long) * 64, s->st));
+                    }
+                }
+                TRY(dev_alloc(s, &s->chain_bar, (size_t)16 * 9));
+                HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * 16 * 9, s->st));
             }
-            TRY(dev_alloc(s, &s->chain_bar, (size_t)16 * 9));
-            HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * 16 * 9, s->st));
         }
         dzg_launch_fast_init(d, s->st);
         if (d.spb) {

@@ -33,7 +33,10 @@ __device__ __forceinline__ double fast_beta_dot(const double *__restrict__ wt,
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (threadIdx.x < 256) {
         int i = threadIdx.x;
-        for (; i + 3 * 256 < m; i += 4 * 256) { // four loads in flight per array and thread
+        // (unrolled: the loads of eight steps leave together -- after a kernel boundary each is a
+        // trip to HBM -- and the sums are then taken in the same order as ever)
+#pragma unroll 8
+        for (; i + 3 * 256 < m; i += 4 * 256) {
             a0 = fma(wt[i], a[i], a0);
             a1 = fma(wt[i + 256], a[i + 256], a1);
             a2 = fma(wt[i + 512], a[i + 512], a2);
@@ -44,9 +47,51 @@ __device__ __forceinline__ double fast_beta_dot(const double *__restrict__ wt,
     return block_sum((a0 + a1) + (a2 + a3));
 }
 
-// One row of dx = Binv a_j by the LPR lanes of a wave that share `i` (lane `sub` of LPR): the
-// compact row of Binv0 against the gathered column `ag` (padded with a zero to an even length),
-// minus the eta file's share.  The summation order depends on LPR, k and neta only.
+// One row of dx = Binv a_j by the LPR lanes of a wave that share `i` (lane `sub` of LPR), in two
+// steps so that a kernel may do the first before beta is known: (head) this lane's share of the
+// compact row of Binv0 against the gathered column `ag` (padded with a zero to an even length);
+// (tail) minus this lane's share of the eta file, then the sum over the LPR lanes.  The summation
+// order depends on LPR, k and neta only.  Rows i >= m: zero (the lanes still take part in the tail).
+template <int LPR>
+__device__ __forceinline__ double fast_gemv_row_head(int i, int m, int k2,
+                                                     const double *__restrict__ binv, long long ldb,
+                                                     const double *__restrict__ ag, int sub)
+{
+    if (i >= m) return 0.0;
+    const double *row = binv + (long long)i * ldb;
+    double a0 = 0.0, a1 = 0.0;
+    int c = 2 * sub;
+    for (; c + 2 * LPR < k2; c += 4 * LPR) {
+        const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
+        const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 2 * LPR);
+        const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+        const double2_t g1 = *reinterpret_cast<const double2_t *>(ag + c + 2 * LPR);
+        a0 = fma(r0.x, g0.x, a0);
+        a1 = fma(r1.x, g1.x, a1);
+        a0 = fma(r0.y, g0.y, a0);
+        a1 = fma(r1.y, g1.y, a1);
+    }
+    for (; c < k2; c += 2 * LPR) {
+        const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
+        const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+        a0 = fma(r0.x, g0.x, a0);
+        a0 = fma(r0.y, g0.y, a0);
+    }
+    return a0 + a1;
+}
+
+template <int LPR>
+__device__ __forceinline__ double fast_gemv_row_tail(double acc, int i, int m, int neta,
+                                                     const double *__restrict__ U, long long ldu,
+                                                     const double *__restrict__ beta, int sub)
+{
+    if (i < m)
+        for (int t = sub; t < neta; t += LPR) acc = fma(-U[(long long)t * ldu + i], beta[t], acc);
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+    return acc;
+}
+
 template <int LPR>
 __device__ __forceinline__ double fast_gemv_row(int i, int m, int k2, int neta,
                                                 const double *__restrict__ binv, long long ldb,
@@ -54,32 +99,28 @@ __device__ __forceinline__ double fast_gemv_row(int i, int m, int k2, int neta,
                                                 const double *__restrict__ U, long long ldu,
                                                 const double *__restrict__ beta, int sub)
 {
+    const double acc = fast_gemv_row_head<LPR>(i, m, k2, binv, ldb, ag, sub);
+    return fast_gemv_row_tail<LPR>(acc, i, m, neta, U, ldu, beta, sub);
+}
+
+// v_r = (row p of Binv)_r = base - sum_t U_t[p] W_t[r]  (BTRAN): the eta file's share, sixteen etas
+// per trip to memory; an eta beyond neta contributes fma(0, 0, acc) = acc exactly.
+__device__ __forceinline__ double fast_btran_eta(int neta, const double *__restrict__ U, long long ldu,
+                                                 const double *__restrict__ W, long long ldw, int p,
+                                                 int r)
+{
     double acc = 0.0;
-    if (i < m) {
-        const double *row = binv + (long long)i * ldb;
-        double a0 = 0.0, a1 = 0.0;
-        int c = 2 * sub;
-        for (; c + 2 * LPR < k2; c += 4 * LPR) {
-            const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-            const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 2 * LPR);
-            const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
-            const double2_t g1 = *reinterpret_cast<const double2_t *>(ag + c + 2 * LPR);
-            a0 = fma(r0.x, g0.x, a0);
-            a1 = fma(r1.x, g1.x, a1);
-            a0 = fma(r0.y, g0.y, a0);
-            a1 = fma(r1.y, g1.y, a1);
-        }
-        for (; c < k2; c += 2 * LPR) {
-            const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
-            const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
-            a0 = fma(r0.x, g0.x, a0);
-            a0 = fma(r0.y, g0.y, a0);
-        }
-        acc = a0 + a1;
-        for (int t = sub; t < neta; t += LPR) acc = fma(-U[(long long)t * ldu + i], beta[t], acc);
-    }
+    for (int t0 = 0; t0 < neta; t0 += 16) {
+        double u[16], w[16];
 #pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+        for (int j = 0; j < 16; ++j) {
+            const bool ok = t0 + j < neta;
+            u[j] = ok ? U[(long long)(t0 + j) * ldu + p] : 0.0;
+            w[j] = ok ? W[(long long)(t0 + j) * ldw + r] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fma(u[j], w[j], acc);
+    }
     return acc;
 }
 
@@ -108,6 +149,7 @@ struct DzgPivotArgs {
     int m, q;
     const double *x, *xbar, *z, *zbar, *dx, *dz, *v;
     int *basis, *nonbasis;
+    int *bcode, *nbcode;
     const int *var_col;
     double *binv;
     long long ldb;
@@ -128,6 +170,7 @@ inline DzgPivotArgs dzg_pivot_args(const DzgDev &d)
     pa.m = d.m; pa.q = d.q;
     pa.x = d.x; pa.xbar = d.xbar; pa.z = d.z; pa.zbar = d.zbar; pa.dx = d.dx; pa.dz = d.dz; pa.v = d.v;
     pa.basis = d.basis; pa.nonbasis = d.nonbasis; pa.var_col = d.var_col;
+    pa.bcode = d.bcode; pa.nbcode = d.nbcode;
     pa.binv = d.binv; pa.ldb = d.ldb; pa.drow = d.drow; pa.dslot = d.dslot;
     pa.W = d.W; pa.ldw = d.ldw; pa.plist = d.plist; pa.pslot = d.pslot;
     pa.col0 = d.col0; pa.col1 = d.col1; pa.cptr = d.csc ? d.cptr : nullptr;
@@ -166,15 +209,17 @@ __device__ __forceinline__ DzgPivotScalars fast_pivot_scalars(double xp, double 
     return ps;
 }
 
-// `ps` need only be valid in thread 0.  chain != 0 (k_chain_post): the other workgroups of the
-// launch are updating the vectors meanwhile, from their own copies of these scalars; the new eta /
-// column counts are committed here (nobody in that launch reads them from the control block), and
-// the 1.0 of a column appended to Binv0 is written by the workgroup that owns row p.
+// `ps` need only be valid in thread 0.  chain != 0 (k_chain_post): ONE WAVE keeps the books (lanes
+// `tid` 0..63, no workgroup barrier inside) while the rest of the launch is updating the vectors,
+// from their own copies of these scalars; the new eta / column counts are committed here (nobody in
+// that launch reads them from the control block), and the 1.0 of a column appended to Binv0 is
+// written by the thread that owns row p.
 __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
                                                    const DzgPivotArgs &pa,
                                                    const DzgPivotScalars &ps, int chain)
 {
-    __shared__ int s_ok, s_k, s_ci, s_cj;
+    __shared__ int sh_ok, sh_k, sh_ci, sh_cj;
+    int s_ok = 0, s_k = 0, s_ci = 0, s_cj = 0; // thread 0's copies; broadcast below
     const int m = pa.m, q = pa.q, col0 = pa.col0, col1 = pa.col1;
     int *basis = pa.basis, *nonbasis = pa.nonbasis, *drow = pa.drow, *dslot = pa.dslot;
     int *plist = pa.plist, *pslot = pa.pslot;
@@ -184,7 +229,8 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
     const long long *cptr = pa.cptr;
     int *log_kind = pa.log_kind, *log_enter = pa.log_enter, *log_leave = pa.log_leave;
     double *log_mu = pa.log_mu, *log_margin = pa.log_margin;
-    const int tid = threadIdx.x;
+    const int tid = chain ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int nthr = chain ? 64 : (int)blockDim.x;
     const int p = c.leave_pos, r = c.enter_pos, neta = c.neta;
     const long long s0 = c.nb_struct;
     // everything addressed by p, r -- issued together, used below
@@ -209,7 +255,24 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
         s_ci = ci;
         s_cj = cj;
     }
-    __syncthreads();
+    if (chain) { // one wave: lane 0's values by shuffle
+        s_ok = __shfl(s_ok, 0, DZG_WAVE);
+        s_k = __shfl(s_k, 0, DZG_WAVE);
+        s_ci = __shfl(s_ci, 0, DZG_WAVE);
+        s_cj = __shfl(s_cj, 0, DZG_WAVE);
+    } else {
+        if (tid == 0) {
+            sh_ok = s_ok;
+            sh_k = s_k;
+            sh_ci = s_ci;
+            sh_cj = s_cj;
+        }
+        __syncthreads();
+        s_ok = sh_ok;
+        s_k = sh_k;
+        s_ci = sh_ci;
+        s_cj = sh_cj;
+    }
     if (!s_ok) return;
     const int ci = s_ci, cj = s_cj;
     // (the eta of this pivot, u = (dx - e_p)/dx_p and w = v, is appended by the update, which
@@ -228,7 +291,7 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
     int del_ce = -1, del_last = -1;
     if (cj < 0) {
         const int re = -1 - cj;
-        for (int t = tid; t < neta; t += blockDim.x) W[(long long)t * ldw + re] = 0.0;
+        for (int t = tid; t < neta; t += nthr) W[(long long)t * ldw + re] = 0.0;
         if (tid == 0) {
             const int ce = dslot[re], last = s_k - 1;
             if (ce != last) {
@@ -262,6 +325,8 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
     ctl->price_bytes = bytes;
     basis[p] = vj;
     nonbasis[r] = vi;
+    pa.bcode[p] = cj;
+    pa.nbcode[r] = ci;
     // nonbasic position r now holds vi instead of vj; the list only tracks OWNED columns
     const bool own_j = cj >= col0 && cj < col1, own_i = ci >= col0 && ci < col1;
     if (cptr) {

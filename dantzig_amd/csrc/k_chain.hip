@@ -119,27 +119,103 @@ struct ChainStamps {
     }
 };
 
-// rows [r0, r1) of workgroup b: the same split in FTRAN, BTRAN and the update
+// ---------------------------------------------------------------------------------
+// Work split.  Workgroup b owns rows [r0, r1) -- thread t the row r0 + t -- in FTRAN, BTRAN and the
+// update, and columns [q0, q1) of z -- thread t the column q0 + t.  (The host runs the chain only
+// when a workgroup's share is at most one row and one column per thread.)  A thread loads what it
+// needs of its row / column as the first thing the kernel does, together with the control block:
+// after a kernel boundary every first touch of a line costs a trip to memory (1-2 us), and these
+// trips are taken side by side instead of one behind the other.
+// ---------------------------------------------------------------------------------
+#define CH_NW (CH_THREADS / 64)
+#define CH_MAXP 16 // FTRAN passes (rows per lane group) whose partial sums wait in registers
+
 __device__ __forceinline__ void chain_rows(int m, int &r0, int &r1)
 {
     const int per = ((m + (int)gridDim.x - 1) / (int)gridDim.x + 3) & ~3;
     r0 = (int)blockIdx.x * per;
-    r1 = r0 + per < m ? r0 + per : m;
     if (r0 > m) r0 = m;
+    r1 = r0 + per < m ? r0 + per : m;
+}
+
+__device__ __forceinline__ void chain_cols(int q, int &q0, int &q1)
+{
+    const int per = (q + (int)gridDim.x - 1) / (int)gridDim.x;
+    q0 = (int)blockIdx.x * per;
+    if (q0 > q) q0 = q;
+    q1 = q0 + per < q ? q0 + per : q;
+}
+
+// up to 4 x 64 partial candidates in the registers of one wave, loaded before their count is known
+struct ChainSpec {
+    double r[4], h[4];
+    int k[4];
+};
+__device__ __forceinline__ void chain_spec_load(ChainSpec &s, const double *__restrict__ pr,
+                                                const int *__restrict__ pk,
+                                                const double *__restrict__ ph, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { // (the arrays hold 4096 entries: reading past `count` is harmless)
+        s.r[j] = pr[lane + 64 * j];
+        s.k[j] = pk[lane + 64 * j];
+        s.h[j] = ph[lane + 64 * j];
+    }
+}
+__device__ __forceinline__ DzgCand2 chain_spec_reduce(const ChainSpec &s, int count, int lane)
+{
+    DzgCand2 best = dzg_cand2_none();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        DzgCand2 o;
+        o.r = s.r[j];
+        o.k = s.k[j];
+        o.h = s.h[j];
+        if (lane + 64 * j < count) best = dzg_better2(best, o);
+    }
+    return dzg_wave_best2(best);
+}
+
+// two argmax candidates through LDS: written by lane 0 of waves 0 and 1, read by everybody
+struct ChainSlots {
+    double r[2], h[2];
+    int k[2];
+};
+__device__ __forceinline__ void chain_put(ChainSlots &s, int slot, const DzgCand2 &c)
+{
+    s.r[slot] = c.r;
+    s.k[slot] = c.k;
+    s.h[slot] = c.h;
+}
+__device__ __forceinline__ DzgCand2 chain_get(const ChainSlots &s, int slot)
+{
+    DzgCand2 c;
+    c.r = s.r[slot];
+    c.k = s.k[slot];
+    c.h = s.h[slot];
+    return c;
+}
+
+// best of the candidates threads 0 .. n-1 hold; valid in wave 0 (n <= 64: no workgroup barrier)
+__device__ __forceinline__ DzgCand2 chain_best(DzgCand2 c, int n)
+{
+    if (n <= 64) return (threadIdx.x < 64) ? dzg_wave_best2(c) : c;
+    return dzg_block_best2(c);
 }
 
 // The entering column gathered to compact coordinates, in LDS (zero-padded to an even length).
+// dr0, dr1 = drow[tid], drow[tid + CH_THREADS], loaded early.
 __device__ __forceinline__ void chain_stage_ag(double *s_ag, int k, int code,
                                                const double *__restrict__ a,
-                                               const int *__restrict__ drow)
+                                               const int *__restrict__ drow, int dr0, int dr1)
 {
-    const int k2 = (k + 1) & ~1;
-    if (code < 0) {
-        const int rr = -1 - code;
-        for (int c = threadIdx.x; c < k2; c += blockDim.x) s_ag[c] = (c < k && drow[c] == rr) ? 1.0 : 0.0;
-    } else {
-        for (int c = threadIdx.x; c < k2; c += blockDim.x) s_ag[c] = c < k ? a[drow[c]] : 0.0;
-    }
+    const int k2 = (k + 1) & ~1, tid = threadIdx.x;
+    const int rr = -1 - code; // (entering slack: the unit vector of its row)
+    if (tid < k2) s_ag[tid] = tid < k ? (code < 0 ? (dr0 == rr ? 1.0 : 0.0) : a[dr0]) : 0.0;
+    if (tid + CH_THREADS < k2)
+        s_ag[tid + CH_THREADS] = tid + CH_THREADS < k ? (code < 0 ? (dr1 == rr ? 1.0 : 0.0) : a[dr1]) : 0.0;
+    for (int c = tid + 2 * CH_THREADS; c < k2; c += CH_THREADS)
+        s_ag[c] = c < k ? (code < 0 ? (drow[c] == rr ? 1.0 : 0.0) : a[drow[c]]) : 0.0;
 }
 
 // beta_t = W_t . a_j by workgroup t, published for everybody
@@ -157,37 +233,49 @@ __device__ __forceinline__ void chain_beta(const DzgDev &d, int neta, int code,
     if (threadIdx.x == 0) st_sc1(d.beta + b, acc);
 }
 
-// dx on this workgroup's rows (+ a primal step's ratio candidates, src/simplex.rs:439-461)
+// FTRAN on this workgroup's rows, first half (needs the gathered column only): lane group `grp` of
+// wave `wave` takes row r0 + (pass * CH_NW + wave) * RPW + grp; the partial sums of the first
+// CH_MAXP passes stay in registers across the barrier beta is waited for.
 template <int LPR>
-__device__ __forceinline__ void chain_gemv(const DzgDev &d, int kind, int k, int neta, int code,
-                                           const double *__restrict__ acolp, const double *s_ag,
-                                           const double *s_beta, double mu, double tau,
-                                           DzgCand2 &best)
+__device__ __forceinline__ void chain_dot_head(const DzgDev &d, int r0, int r1, int k,
+                                               const double *s_ag, double (&accs)[CH_MAXP])
 {
     constexpr int RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR, grp = lane / LPR;
     const int k2 = (k + 1) & ~1;
-    int r0, r1;
-    chain_rows(d.m, r0, r1);
-    for (int i0 = r0 + wave * RPW; i0 < r1; i0 += nw * RPW) {
-        const int i = i0 + grp;
-        const int ii = i < r1 ? i : d.m; // rows beyond the chunk belong to the next workgroup
-        double acc = fast_gemv_row<LPR>(ii, d.m, k2, neta, d.binv, d.ldb, s_ag, d.U, d.ldw, s_beta, sub);
-        if (ii < d.m && sub == 0) {
-            acc = fast_gemv_unit(acc, d.var_col[d.basis[i]], code, acolp);
-            d.dx[i] = acc;
-            if (kind == DZG_STEP_PRIMAL) {
-                const double xi = d.x[i], scaled = mu * d.xbar[i];
-                const double den = xi + scaled;
-                DzgCand2 cnd;
-                cnd.r = dzg_div(acc, den);
-                cnd.k = i;
-                cnd.h = -__builtin_inf();
-                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
-                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
-            }
+#pragma unroll
+    for (int pass = 0; pass < CH_MAXP; ++pass) {
+        const int i = r0 + (pass * CH_NW + wave) * RPW + grp;
+        accs[pass] = fast_gemv_row_head<LPR>(i < r1 ? i : d.m, d.m, k2, d.binv, d.ldb, s_ag, sub);
+    }
+}
+
+// second half: the eta file's share and the sum over the lanes; row sums land in s_dx[row - r0]
+template <int LPR>
+__device__ __forceinline__ void chain_dot_tail(const DzgDev &d, int r0, int r1, int k, int neta,
+                                               const double *s_ag, const double *s_beta,
+                                               const double (&accs)[CH_MAXP], double *s_dx)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int k2 = (k + 1) & ~1;
+    const int npass = (r1 - r0 + CH_NW * RPW - 1) / (CH_NW * RPW);
+#pragma unroll
+    for (int pass = 0; pass < CH_MAXP; ++pass) {
+        if (pass < npass) { // (block-uniform)
+            const int i = r0 + (pass * CH_NW + wave) * RPW + grp;
+            const int ii = i < r1 ? i : d.m;
+            const double acc = fast_gemv_row_tail<LPR>(accs[pass], ii, d.m, neta, d.U, d.ldw, s_beta, sub);
+            if (ii < d.m && sub == 0) s_dx[i - r0] = acc;
         }
+    }
+    for (int pass = CH_MAXP; pass < npass; ++pass) { // very tall shares: the whole row now
+        const int i = r0 + (pass * CH_NW + wave) * RPW + grp;
+        const int ii = i < r1 ? i : d.m;
+        const double acc = fast_gemv_row<LPR>(ii, d.m, k2, neta, d.binv, d.ldb, s_ag, d.U, d.ldw, s_beta, sub);
+        if (ii < d.m && sub == 0) s_dx[i - r0] = acc;
     }
 }
 
@@ -198,25 +286,51 @@ __device__ __forceinline__ void chain_gemv(const DzgDev &d, int kind, int k, int
 __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsigned long long *bar,
                                                           unsigned long long *dbg)
 {
+    __shared__ double s_ag[CH_AGCAP];
+    __shared__ double s_beta[R_], s_dx[CH_THREADS];
+    __shared__ ChainSlots s_c;
     ChainStamps ts;
     ts.start(dbg);
-    __shared__ double s_ag[CH_AGCAP];
-    __shared__ double s_beta[R_], s_up[R_];
     DzgCtl *ctl = d.ctl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = d.m, nwg = (int)gridDim.x;
+    const bool lead = blockIdx.x == 0 && tid == 0;
+    // ---- first touches, side by side: candidates of the last update, this thread's row
+    ChainSpec sp;
+    if (wave == 0)
+        chain_spec_load(sp, d.fpz_r, d.fpz_k, d.fpz_h, lane);
+    else if (wave == 1)
+        chain_spec_load(sp, d.fpx_r, d.fpx_k, d.fpx_h, lane);
+    int r0, r1;
+    chain_rows(m, r0, r1);
+    const int row = r0 + tid;
+    const bool has_row = row < r1;
+    int dslot_i = -1, bcode_i = 0;
+    double x_i = 0.0, xbar_i = 0.0;
+    if (has_row) {
+        dslot_i = d.dslot[row];
+        bcode_i = d.bcode[row];
+        x_i = d.x[row];
+        xbar_i = d.xbar[row];
+    }
     DzgCtl c = *ctl; // one snapshot; nothing the lead lane writes below is read from it
     if (c.status != DZG_RUNNING) return;
-    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-    const int m = d.m, nwg = (int)gridDim.x;
     unsigned long long gen = c.bar_gen;
     const int neta = c.neta, k = c.ncompact;
-    const DzgCand2 cj = reduce_partials(d.fpz_r, d.fpz_k, d.fpz_h, c.fp_count);
-    const DzgCand2 ci = reduce_partials(d.fpx_r, d.fpx_k, d.fpx_h, c.fp_count);
+    const int dr0 = tid < k ? d.drow[tid] : -1;
+    const int dr1 = tid + CH_THREADS < k ? d.drow[tid + CH_THREADS] : -1;
+    if (wave < 2) {
+        const DzgCand2 w = chain_spec_reduce(sp, c.fp_count, lane);
+        if (lane == 0) chain_put(s_c, wave, w);
+    }
+    __syncthreads();
+    const DzgCand2 cj = chain_get(s_c, 0), ci = chain_get(s_c, 1);
     int kind;
     double mu;
     if (!fast_status(ctl, c, lead, cj, ci, d.eps, m, false, kind, &mu)) return;
     const int slot = kind == DZG_STEP_PRIMAL ? 0 : 1;
-    ts.mark(slot); // 0: snapshot + status
-    if (k > CH_AGCAP) { // the host switches to the seven launches before this can happen
+    ts.mark(slot); // 0: first touches + status
+    if (k > CH_AGCAP || c.fp_count > 256) { // the host runs the seven launches before this can happen
         if (lead) ctl->status = DZG_PANIC;
         return;
     }
@@ -227,44 +341,81 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
     int p;
     if (kind == DZG_STEP_PRIMAL) {
         const int epos = cj.k;
-        const int code = d.var_col[d.nonbasis[epos]];
+        const int code = d.nbcode[epos];
+        double zr = 0.0, zbr = 0.0;
         if (lead) {
-            ctl->enter_code = code;
-            ctl->zr = d.z[epos];
-            ctl->zbar_r = d.zbar[epos];
-            ctl->enter_dslot = code < 0 ? d.dslot[-1 - code] : -1;
+            zr = d.z[epos];
+            zbr = d.zbar[epos];
         }
         const double *a = code < 0 ? nullptr : d.A + (long long)(code - d.col0) * d.lda;
+        // this row's unit-column share of dx (fast_gemv_unit's term), loaded beside the gather
+        const bool has_unit = has_row && bcode_i < 0;
+        double unit_i = 0.0;
+        if (has_unit) unit_i = code >= 0 ? a[-1 - bcode_i] : (code == bcode_i ? 1.0 : 0.0);
+        int edslot = -1;
+        if (lead && code < 0) edslot = d.dslot[-1 - code];
+        chain_stage_ag(s_ag, k, code, a, d.drow, dr0, dr1);
         chain_beta(d, neta, code, a);
-        chain_stage_ag(s_ag, k, code, a, d.drow);
-        ts.mark(slot); // 1: beta + gather
+        if (lead) {
+            ctl->enter_code = code;
+            ctl->zr = zr;
+            ctl->zbar_r = zbr;
+            ctl->enter_dslot = edslot;
+        }
+        __syncthreads(); // the gathered column is complete
+        double accs[CH_MAXP];
+        if (k > 512)
+            chain_dot_head<64>(d, r0, r1, k, s_ag, accs);
+        else
+            chain_dot_head<16>(d, r0, r1, k, s_ag, accs);
+        ts.mark(slot); // 1: beta, gather, Binv0 rows
         if (!chain_barrier(ctl, bar, gen)) return;
         ts.mark(slot); // 2: barrier
-        if (threadIdx.x < R_) s_beta[threadIdx.x] = (int)threadIdx.x < neta ? ld_sc1(d.beta + threadIdx.x) : 0.0;
+        if (tid < R_) s_beta[tid] = tid < neta ? ld_sc1(d.beta + tid) : 0.0;
         __syncthreads();
-        DzgCand2 best = dzg_cand2_none();
         if (k > 512)
-            chain_gemv<64>(d, kind, k, neta, code, a, s_ag, s_beta, mu, c.tau, best);
+            chain_dot_tail<64>(d, r0, r1, k, neta, s_ag, s_beta, accs, s_dx);
         else
-            chain_gemv<16>(d, kind, k, neta, code, a, s_ag, s_beta, mu, c.tau, best);
-        best = dzg_block_best2(best);
-        if (threadIdx.x == 0) {
+            chain_dot_tail<16>(d, r0, r1, k, neta, s_ag, s_beta, accs, s_dx);
+        __syncthreads();
+        // ratio test on this thread's row (src/simplex.rs:439-461)
+        DzgCand2 best = dzg_cand2_none();
+        if (has_row) {
+            double dxi = s_dx[tid];
+            if (has_unit) dxi += unit_i;
+            d.dx[row] = dxi;
+            const double scaled = mu * xbar_i;
+            const double den = x_i + scaled;
+            DzgCand2 cnd;
+            cnd.r = dzg_div(dxi, den);
+            cnd.k = row;
+            cnd.h = -__builtin_inf();
+            if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+            if (dzg_noise_zero(den, x_i, scaled, c.tau)) best.h = __builtin_inf();
+        }
+        best = chain_best(best, r1 - r0);
+        if (tid == 0) {
             st_sc1(d.rx_r + blockIdx.x, best.r);
             st_sc1(d.rx_k + blockIdx.x, best.k);
             st_sc1(d.rx_h + blockIdx.x, best.h);
         }
-        ts.mark(slot); // 3: FTRAN rows + candidates
+        ts.mark(slot); // 3: eta share, candidates
         if (!chain_barrier(ctl, bar, gen)) return;
         ts.mark(slot); // 4: barrier
-        DzgCand2 cw = dzg_cand2_none();
-        for (int i = threadIdx.x; i < nwg; i += blockDim.x) {
-            DzgCand2 o;
-            o.r = ld_sc1(d.rx_r + i);
-            o.k = ld_sc1(d.rx_k + i);
-            o.h = ld_sc1(d.rx_h + i);
-            cw = dzg_better2(cw, o);
+        if (wave == 0) {
+            DzgCand2 w = dzg_cand2_none();
+            for (int i = lane; i < nwg; i += 64) {
+                DzgCand2 o;
+                o.r = ld_sc1(d.rx_r + i);
+                o.k = ld_sc1(d.rx_k + i);
+                o.h = ld_sc1(d.rx_h + i);
+                w = dzg_better2(w, o);
+            }
+            w = dzg_wave_best2(w);
+            if (lane == 0) chain_put(s_c, 0, w);
         }
-        cw = dzg_block_best2(cw);
+        __syncthreads();
+        const DzgCand2 cw = chain_get(s_c, 0);
         if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_UNBOUNDED)) { // :313
             if (lead) ctl->bar_gen = gen;
             return;
@@ -275,25 +426,17 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
     } else {
         p = ci.k;
     }
+    // ---- BTRAN: v = row p of Binv on this thread's row; one trip: nothing below waits for another load
+    const int lcode = d.bcode[p];
+    if (has_row) {
+        const double base = dslot_i >= 0 ? d.binv[(long long)p * d.ldb + dslot_i] : (lcode == -1 - row ? 1.0 : 0.0);
+        d.v[row] = base - fast_btran_eta(neta, d.U, d.ldw, d.W, d.ldw, p, row);
+    }
     if (lead) {
         ctl->xp = d.x[p];
         ctl->xbp = d.xbar[p];
-        ctl->leave_code = d.var_col[d.basis[p]];
+        ctl->leave_code = lcode;
         if (gen != c.bar_gen) ctl->bar_gen = gen;
-    }
-    // ---- BTRAN: v = row p of Binv on this workgroup's rows
-    const int lcode = d.var_col[d.basis[p]];
-    __syncthreads();
-    if (threadIdx.x < R_) s_up[threadIdx.x] = (int)threadIdx.x < neta ? d.U[(long long)threadIdx.x * d.ldw + p] : 0.0;
-    __syncthreads();
-    int r0, r1;
-    chain_rows(m, r0, r1);
-    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const int slot = d.dslot[r];
-        const double base = slot >= 0 ? d.binv[(long long)p * d.ldb + slot] : (lcode == -1 - r ? 1.0 : 0.0);
-        double acc = 0.0;
-        for (int t = 0; t < neta; ++t) acc = fma(s_up[t], d.W[(long long)t * d.ldw + r], acc);
-        d.v[r] = base - acc;
     }
     ts.mark(slot); // primal 6 / dual 1: BTRAN row
     ts.done(slot);
@@ -301,27 +444,73 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
 
 // ---------------------------------------------------------------------------------
 // k_chain_post: a dual step's ratio test and FTRAN (src/simplex.rs:324-325, :226-229), the pivot's
-// books (fast_rows.h), pivot() x4 (:262-265, :410-421) with the eta append, and the first-pivot
-// candidates of the next iteration (:423-437).  only_partials != 0: the candidates only.
+// books (fast_rows.h; the last wave of workgroup 0, beside everybody's update), pivot() x4
+// (:262-265, :410-421) with the eta append, and the first-pivot candidates of the next iteration
+// (:423-437).  only_partials != 0: the candidates only.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsigned long long *bar,
                                                            const DzgPivotArgs pa, int only_partials,
                                                            int nrz, unsigned long long *dbg)
 {
+    __shared__ double s_ag[CH_AGCAP];
+    __shared__ double s_beta[R_], s_dx[CH_THREADS];
+    __shared__ double s_dxp;
+    __shared__ ChainSlots s_c;
     ChainStamps ts;
     ts.start(only_partials ? nullptr : dbg);
     int slot = 2;
-    __shared__ double s_ag[CH_AGCAP];
-    __shared__ double s_beta[R_];
-    __shared__ double s_dxp;
     DzgCtl *ctl = d.ctl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = d.m, q = d.q;
+    const bool lead = blockIdx.x == 0 && tid == 0;
+    // ---- first touches, side by side: the pricing pass's candidates, this thread's row and column
+    DzgCand2 mine = dzg_cand2_none();
+    ChainSpec sp;
+    const bool one_wave = nrz <= 256; // (block-uniform) the candidates fit one wave's registers
+    if (!only_partials && one_wave) {
+        if (wave == 0) chain_spec_load(sp, d.rz_r, d.rz_k, d.rz_h, lane);
+    } else if (!only_partials) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { // (4096 entries: harmless past nrz; a primal step ignores them)
+            const int i = tid + CH_THREADS * j;
+            DzgCand2 o;
+            o.r = d.rz_r[i];
+            o.k = d.rz_k[i];
+            o.h = d.rz_h[i];
+            if (i < nrz) mine = dzg_better2(mine, o);
+        }
+        for (int i = tid + 4 * CH_THREADS; i < nrz; i += CH_THREADS) {
+            DzgCand2 o;
+            o.r = d.rz_r[i];
+            o.k = d.rz_k[i];
+            o.h = d.rz_h[i];
+            mine = dzg_better2(mine, o);
+        }
+    }
+    int r0, r1, q0, q1;
+    chain_rows(m, r0, r1);
+    chain_cols(q, q0, q1);
+    const int row = r0 + tid, col = q0 + tid;
+    const bool has_row = row < r1, has_col = col < q1;
+    double x_i = 0.0, xbar_i = 0.0, v_i = 0.0, dx_i = 0.0, z_k = 0.0, zbar_k = 0.0, dz_k = 0.0;
+    int bcode_i = 0;
+    if (has_row) {
+        x_i = d.x[row];
+        xbar_i = d.xbar[row];
+        if (!only_partials) {
+            v_i = d.v[row];
+            dx_i = d.dx[row]; // (a dual step computes its own below)
+            bcode_i = d.bcode[row];
+        }
+    }
+    if (has_col) {
+        z_k = d.z[col];
+        zbar_k = d.zbar[col];
+        if (!only_partials) dz_k = d.dz[col];
+    }
     DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
-    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-    const int m = d.m, q = d.q;
     unsigned long long gen = c.bar_gen;
-    int r0, r1;
-    chain_rows(m, r0, r1);
     // what the update needs (all block-uniform)
     int p = 0, r = 0, teta = 0, wzero = -1, del_ce = -1, del_last = -1, app_col = -1;
     double t = 0.0, s = 0.0, tbar = 0.0, sbar = 0.0, rdxp = 0.0, tau = c.tau;
@@ -332,54 +521,83 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
         p = c.leave_pos;
         int cj, edslot;
         double zr, zbr, dzr, dxp;
-        bool books_wg;
         if (kind == DZG_STEP_DUAL) {
-            const DzgCand2 cw = reduce_partials(d.rz_r, d.rz_k, d.rz_h, nrz);
+            const int dr0 = tid < k ? d.drow[tid] : -1;
+            const int dr1 = tid + CH_THREADS < k ? d.drow[tid + CH_THREADS] : -1;
+            DzgCand2 cw;
+            if (one_wave) {
+                if (wave == 0) {
+                    const DzgCand2 w = chain_spec_reduce(sp, nrz, lane);
+                    if (lane == 0) chain_put(s_c, 0, w);
+                }
+                __syncthreads();
+                cw = chain_get(s_c, 0);
+            } else {
+                cw = dzg_block_best2(mine);
+            }
             if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_INFEASIBLE)) return; // :325
             slot = 3;
-            ts.mark(slot); // 0: snapshot + ratio test
+            ts.mark(slot); // 0: first touches + ratio test
             r = cw.k;
-            cj = d.var_col[d.nonbasis[r]];
-            // read now: nobody rewrites them before the barrier below
+            cj = d.nbcode[r];
             zr = d.z[r];
             zbr = d.zbar[r];
             dzr = d.dz[r];
+            const double *a = cj < 0 ? nullptr : d.A + (long long)(cj - d.col0) * d.lda;
             edslot = cj < 0 ? d.dslot[-1 - cj] : -1;
+            const bool has_unit = has_row && bcode_i < 0;
+            double unit_i = 0.0, unit_p = 0.0;
+            if (has_unit) unit_i = cj >= 0 ? a[-1 - bcode_i] : (cj == bcode_i ? 1.0 : 0.0);
+            if (ci < 0) unit_p = cj >= 0 ? a[-1 - ci] : (cj == ci ? 1.0 : 0.0);
+            chain_stage_ag(s_ag, k, cj, a, d.drow, dr0, dr1);
+            chain_beta(d, neta, cj, a);
             if (lead) {
                 ctl->enter_pos = r;
                 ctl->enter_code = cj;
             }
             c.enter_pos = r;
             c.enter_code = cj;
-            const double *a = cj < 0 ? nullptr : d.A + (long long)(cj - d.col0) * d.lda;
-            chain_beta(d, neta, cj, a);
-            chain_stage_ag(s_ag, k, cj, a, d.drow);
-            ts.mark(slot); // 1: loads, beta, gather
+            __syncthreads(); // the gathered column is complete
+            // Binv0's share of this workgroup's rows, and of row p: every workgroup computes dx_p
+            // itself (the arithmetic of the row's owner, so the same bits) and then needs nobody
+            // else's result for the step lengths
+            const int k2 = (k + 1) & ~1;
+            double accs[CH_MAXP], accp;
+            if (k > 512) {
+                chain_dot_head<64>(d, r0, r1, k, s_ag, accs);
+                accp = fast_gemv_row_head<64>(wave == CH_NW - 1 ? p : m, m, k2, d.binv, d.ldb, s_ag, lane);
+            } else {
+                chain_dot_head<16>(d, r0, r1, k, s_ag, accs);
+                accp = fast_gemv_row_head<16>(wave == CH_NW - 1 && lane < 16 ? p : m, m, k2, d.binv, d.ldb, s_ag,
+                                              lane % 16);
+            }
+            ts.mark(slot); // 1: loads, beta, gather, Binv0 rows
             if (!chain_barrier(ctl, bar, gen)) return;
             ts.mark(slot); // 2: barrier
-            if (threadIdx.x < R_) s_beta[threadIdx.x] = (int)threadIdx.x < neta ? ld_sc1(d.beta + threadIdx.x) : 0.0;
+            if (tid < R_) s_beta[tid] = tid < neta ? ld_sc1(d.beta + tid) : 0.0;
             __syncthreads();
-            // dx_p by every workgroup itself (the arithmetic of the row's owner, so the same bits):
-            // the step lengths then need nobody else's result
-            const int k2 = (k + 1) & ~1;
-            if (threadIdx.x < 64) {
-                double acc;
-                if (k > 512)
-                    acc = fast_gemv_row<64>(p, m, k2, neta, d.binv, d.ldb, s_ag, d.U, d.ldw, s_beta, threadIdx.x);
-                else
-                    acc = fast_gemv_row<16>(threadIdx.x < 16 ? p : m, m, k2, neta, d.binv, d.ldb, s_ag, d.U,
-                                            d.ldw, s_beta, threadIdx.x % 16);
-                if (threadIdx.x == 0) s_dxp = fast_gemv_unit(acc, ci, cj, a);
+            if (k > 512) {
+                chain_dot_tail<64>(d, r0, r1, k, neta, s_ag, s_beta, accs, s_dx);
+                if (wave == CH_NW - 1) {
+                    const double acc = fast_gemv_row_tail<64>(accp, p, m, neta, d.U, d.ldw, s_beta, lane);
+                    if (lane == 0) s_dxp = ci < 0 ? acc + unit_p : acc;
+                }
+            } else {
+                chain_dot_tail<16>(d, r0, r1, k, neta, s_ag, s_beta, accs, s_dx);
+                if (wave == CH_NW - 1) {
+                    const double acc = fast_gemv_row_tail<16>(accp, lane < 16 ? p : m, m, neta, d.U, d.ldw,
+                                                              s_beta, lane % 16);
+                    if (lane == 0) s_dxp = ci < 0 ? acc + unit_p : acc;
+                }
             }
-            DzgCand2 unused = dzg_cand2_none();
-            if (k > 512)
-                chain_gemv<64>(d, kind, k, neta, cj, a, s_ag, s_beta, 0.0, 0.0, unused);
-            else
-                chain_gemv<16>(d, kind, k, neta, cj, a, s_ag, s_beta, 0.0, 0.0, unused);
             __syncthreads();
             dxp = s_dxp;
-            books_wg = p >= r0 && p < r1;
-            ts.mark(slot); // 3: FTRAN rows + dx_p
+            if (has_row) {
+                dx_i = s_dx[tid];
+                if (has_unit) dx_i += unit_i;
+                d.dx[row] = dx_i;
+            }
+            ts.mark(slot); // 3: eta share
         } else {
             r = c.enter_pos;
             cj = c.enter_code;
@@ -388,12 +606,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             dzr = d.dz[r];
             edslot = c.enter_dslot;
             dxp = d.dx[p];
-            books_wg = blockIdx.x == 0;
-            ts.mark(slot); // 0: snapshot + loads
+            ts.mark(slot); // 0: first touches
         }
         const DzgPivotScalars ps = fast_pivot_scalars(xp, xbp, dxp, zr, zbr, dzr, neta, c.max_pivot_err);
         const bool appended = ci < 0, deleted = cj < 0;
-        if (books_wg) {
+        if (blockIdx.x == 0 && wave == CH_NW - 1) { // one wave keeps the books
             c.neta = neta;
             c.ncompact = k;
             fast_pivot_books_s(ctl, c, pa, ps, 1);
@@ -407,8 +624,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             del_ce = edslot;
         }
         if (appended) app_col = k;
-        // a column about to be deleted is still being read by the FTRAN rows of slower workgroups
-        if (kind == DZG_STEP_DUAL && deleted && !chain_barrier(ctl, bar, gen)) return;
         if (lead && gen != c.bar_gen) ctl->bar_gen = gen;
         t = ps.t;
         s = ps.s;
@@ -417,72 +632,66 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
         teta = neta; // index of the eta appended now
         wzero = cj < 0 ? -1 - cj : -1;
         rdxp = 1.0 / dxp;
-        if (c.tie_tol >= 0.0) { // the tolerance the books have just set
+        if (c.tie_tol >= 0.0) { // the tolerance the books are setting
             const double adaptive = 64.0 * ps.max_err;
             tau = adaptive > c.tie_tol ? adaptive : c.tie_tol;
         }
-        ts.mark(slot); // primal 1 / dual 4: step lengths (+ books in workgroup 0 / the owner)
+        ts.mark(slot); // primal 1 / dual 4: step lengths
     }
-    // ---- update of this workgroup's rows and columns; candidates on the updated values
+    // ---- update of this thread's row and column; candidates on the updated values
     const double inf = __builtin_inf();
-    double *ut = d.U + (long long)teta * d.ldw;
-    double *wt = d.W + (long long)teta * d.ldw;
     DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
-    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
-        double xi = d.x[i], xb = d.xbar[i];
+    if (has_row) {
+        double xi = x_i, xb = xbar_i;
         if (!only_partials) {
-            const double dd = d.dx[i];
-            const double a = t * dd, b = tbar * dd;
-            xi = (i == p) ? t : xi - a;
-            xb = (i == p) ? tbar : xb - b;
-            d.x[i] = xi;
-            d.xbar[i] = xb;
-            ut[i] = (i == p ? dd - 1.0 : dd) * rdxp;
-            wt[i] = (i == wzero) ? 0.0 : d.v[i];
+            const double a = t * dx_i, b = tbar * dx_i;
+            xi = (row == p) ? t : xi - a;
+            xb = (row == p) ? tbar : xb - b;
+            d.x[row] = xi;
+            d.xbar[row] = xb;
+            d.U[(long long)teta * d.ldw + row] = (row == p ? dx_i - 1.0 : dx_i) * rdxp;
+            d.W[(long long)teta * d.ldw + row] = (row == wzero) ? 0.0 : v_i;
             // Binv0's columns: a leaving slack appends e_p, an entering slack deletes its column
-            // (the last one takes its place)
-            double *row = d.binv + (long long)i * d.ldb;
+            // (the last one takes its place).  Nobody reads Binv0 any more in this launch.
+            double *brow = d.binv + (long long)row * d.ldb;
             if (del_last >= 0) {
-                const double last_val = (app_col == del_last) ? (i == p ? 1.0 : 0.0) : row[del_last];
-                if (del_ce != del_last) row[del_ce] = last_val;
-                row[del_last] = 0.0;
-            } else if (app_col >= 0 && i == p) {
-                row[app_col] = 1.0;
+                const double last_val = (app_col == del_last) ? (row == p ? 1.0 : 0.0) : brow[del_last];
+                if (del_ce != del_last) brow[del_ce] = last_val;
+                brow[del_last] = 0.0;
+            } else if (app_col >= 0 && row == p) {
+                brow[app_col] = 1.0;
             }
         }
         if (xb > 0.0) {
             DzgCand2 cn;
             cn.r = dzg_div(-xi, xb);
-            cn.k = i;
+            cn.k = row;
             cn.h = -inf;
             if (cn.r == cn.r) bx = dzg_better2(bx, cn);
         }
         if (fabs(xb) <= tau && !(xi > tau)) bx.h = inf;
     }
-    const int qper = (q + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int q0 = (int)blockIdx.x * qper, q1 = q0 + qper < q ? q0 + qper : q;
-    for (int kk = q0 + threadIdx.x; kk < q1; kk += blockDim.x) {
-        double zk = d.z[kk], zb = d.zbar[kk];
+    if (has_col) {
+        double zk = z_k, zb = zbar_k;
         if (!only_partials) {
-            const double dd = d.dz[kk];
-            const double a = s * dd, b = sbar * dd;
-            zk = (kk == r) ? s : zk - a;
-            zb = (kk == r) ? sbar : zb - b;
-            d.z[kk] = zk;
-            d.zbar[kk] = zb;
+            const double a = s * dz_k, b = sbar * dz_k;
+            zk = (col == r) ? s : zk - a;
+            zb = (col == r) ? sbar : zb - b;
+            d.z[col] = zk;
+            d.zbar[col] = zb;
         }
         if (zb > 0.0) {
             DzgCand2 cn;
             cn.r = dzg_div(-zk, zb);
-            cn.k = kk;
+            cn.k = col;
             cn.h = -inf;
             if (cn.r == cn.r) bz = dzg_better2(bz, cn);
         }
         if (fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
     }
-    bx = dzg_block_best2(bx);
-    bz = dzg_block_best2(bz);
-    if (threadIdx.x == 0) {
+    bx = chain_best(bx, r1 - r0);
+    bz = chain_best(bz, q1 - q0);
+    if (tid == 0) {
         d.fpx_r[blockIdx.x] = bx.r;
         d.fpx_k[blockIdx.x] = bx.k;
         d.fpx_h[blockIdx.x] = bx.h;

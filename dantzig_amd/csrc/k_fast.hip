@@ -507,10 +507,16 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
                                                    const int *__restrict__ nonbasis,
                                                    const int *__restrict__ var_col, int *plist,
                                                    int *pslot, int col0, int col1,
-                                                   const long long *__restrict__ cptr, int *drow)
+                                                   const long long *__restrict__ cptr, int *drow,
+                                                   const int *__restrict__ basis, int *bcode,
+                                                   int *nbcode)
 {
     // single workgroup: the structural-position list must be built in position order
-    for (int r = threadIdx.x; r < m; r += blockDim.x) dslot[r] = -1;
+    for (int r = threadIdx.x; r < m; r += blockDim.x) {
+        dslot[r] = -1;
+        bcode[r] = var_col[basis[r]];
+    }
+    for (int k = threadIdx.x; k < q; k += blockDim.x) nbcode[k] = var_col[nonbasis[k]];
     __syncthreads();
     if (threadIdx.x == 0) {
         int s = 0;
@@ -634,7 +640,8 @@ void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
     hipMemsetAsync(d.Wc, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
     hipLaunchKernelGGL(k_fast_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.dslot, d.nonbasis,
-                       d.var_col, d.plist, d.pslot, d.col0, d.col1, d.csc ? d.cptr : nullptr, d.drow);
+                       d.var_col, d.plist, d.pslot, d.col0, d.col1, d.csc ? d.cptr : nullptr, d.drow,
+                       d.basis, d.bcode, d.nbcode);
 }
 
 void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,
