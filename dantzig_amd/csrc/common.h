@@ -73,7 +73,7 @@ struct DzgCtl {
     int leave_code;       // column code of the leaving variable
     int enter_dslot;      // compact column of the entering slack's row (entering slack only)
     int neta_cur, k_cur;  // neta and ncompact of the iteration in flight
-    int pad3;
+    int bar_timeout;      // a device-wide barrier gave up waiting (status is DZG_PANIC then)
     double xp, xbp;       // x, xbar at the leaving position
     unsigned long long bar_gen; // device-wide barriers passed so far (k_chain.hip)
 };

@@ -935,6 +935,10 @@ static int run_fast(dzg_solver *s)
         s->since_refactor += batch;
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
+        if (s->h_ctl->bar_timeout)
+            return fail(DZG_E_DEVICE, "a device-wide barrier of the three-launch iteration timed out: its "
+                                      "workgroups were not all resident (is another kernel holding CUs or "
+                                      "LDS on this device?); opts.seven_launches = 1 runs without barriers");
         collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
         bool stop = false;

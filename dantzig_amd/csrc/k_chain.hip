@@ -86,7 +86,10 @@ __device__ __forceinline__ bool chain_barrier(DzgCtl *ctl, unsigned long long *b
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (!ok) ctl->status = DZG_PANIC; // a workgroup never arrived: give up, loudly
+        if (!ok) { // a workgroup never arrived: give up, loudly (the host turns this into an error)
+            ctl->status = DZG_PANIC;
+            ctl->bar_timeout = 1;
+        }
         s_bar_ok = ok;
     }
     __syncthreads();
