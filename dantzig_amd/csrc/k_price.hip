@@ -94,7 +94,9 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
         launch_csc(d, d.plist, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, kernel == DZG_PRICE_SEQ, st);
         return;
     }
-    launch(kernel, d.col1 - d.col0, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nonbasis, d.var_col, d.v, d.dz, d.z,
+    // (column codes per nonbasic position, kept by the pivot's books: one load instead of
+    // nonbasis[] -> var_col[] before a wave knows where its columns are)
+    launch(kernel, d.col1 - d.col0, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nbcode, nullptr, d.v, d.dz, d.z,
            d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, st);
 }
 
