@@ -71,7 +71,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_fast_select_prep(
     DzgCtl *ctl, int m, const double *__restrict__ A, long long lda, int col0,
     const double *__restrict__ xrecv, long long xstride,
-    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const int *__restrict__ nbcode,
     const double *__restrict__ fpx_r, const int *__restrict__ fpx_k,
     const double *__restrict__ fpx_h, const double *__restrict__ fpz_r,
     const int *__restrict__ fpz_k, const double *__restrict__ fpz_h,
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_fast_select_prep(
         if (lead) ctl->enter_pos = epos;
     }
     // ---- FTRAN preparation for the entering variable
-    const int code = code_known ? code_val : var_col[nonbasis[epos]];
+    const int code = code_known ? code_val : nbcode[epos];
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->enter_code = code;
     const double *a = dzg_enter_col(&c, code, A, lda, col0, xrecv, xstride);
     const int neta = c.neta, k = c.ncompact;
@@ -199,8 +199,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
                                           const double *__restrict__ U, long long ldu,
                                           const double *__restrict__ beta,
                                           const double *__restrict__ acolp,
-                                          const int *__restrict__ basis,
-                                          const int *__restrict__ var_col,
+                                          const int *__restrict__ bcode,
                                           const double *__restrict__ x,
                                           const double *__restrict__ xbar,
                                           double *__restrict__ dx, DzgCand2 &best, int want_row,
@@ -217,7 +216,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
         const int i = i0 + grp;
         double acc = fast_gemv_row<LPR>(i, m, k2, neta, binv, ldb, ag, U, ldu, beta, sub);
         if (i < m && sub == 0) {
-            acc = fast_gemv_unit(acc, var_col[basis[i]], code, acolp);
+            acc = fast_gemv_unit(acc, bcode[i], code, acolp);
             dx[i] = acc;
             if (i == want_row) *want_dx = acc; // (LDS: the row whose dx the pivot's books need)
             if (need_kind == DZG_STEP_PRIMAL) {
@@ -239,8 +238,7 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
     DzgCtl *ctl, int need_kind, int m, const double *__restrict__ binv, long long ldb,
     const double *__restrict__ ag, const double *__restrict__ U, long long ldu,
     const double *__restrict__ beta, const double *__restrict__ A, long long lda, int col0,
-    const double *__restrict__ xrecv, long long xstride, const int *__restrict__ basis,
-    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const double *__restrict__ xrecv, long long xstride, const int *__restrict__ bcode,
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
     double *__restrict__ rx_r, int *__restrict__ rx_k, double *__restrict__ rx_h,
     DzgPivotArgs pa)
@@ -266,11 +264,11 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
     const int rpw = k > 512 ? 1 : 4;
     const bool owner = PIVOT && ((p / rpw) % nwaves) / (int)(blockDim.x >> 6) == (int)blockIdx.x;
     if (k > 512)
-        gemv_rows<64>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
-                      var_col, x, xbar, dx, best, p, &s_dxp);
+        gemv_rows<64>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, bcode,
+                      x, xbar, dx, best, p, &s_dxp);
     else
-        gemv_rows<16>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, basis,
-                      var_col, x, xbar, dx, best, p, &s_dxp);
+        gemv_rows<16>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, bcode,
+                      x, xbar, dx, best, p, &s_dxp);
     if (need_kind == DZG_STEP_PRIMAL) {
         best = dzg_block_best2(best);
         if (threadIdx.x == 0) {
@@ -292,7 +290,7 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fast_btran(
     DzgCtl *ctl, int m, const double *__restrict__ binv, long long ldb,
-    const int *__restrict__ dslot, const int *__restrict__ basis, const int *__restrict__ var_col,
+    const int *__restrict__ dslot, const int *__restrict__ bcode,
     const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
     const double *__restrict__ rx_r, const int *__restrict__ rx_k,
     const double *__restrict__ rx_h, double *__restrict__ v)
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(256) void k_fast_btran(
     if (r >= m) return;
     const int slot = dslot[r];
     const double base = slot >= 0 ? binv[(long long)p * ldb + slot]
-                                  : (var_col[basis[p]] == -1 - r ? 1.0 : 0.0);
+                                  : (bcode[p] == -1 - r ? 1.0 : 0.0);
     double acc = 0.0;
     for (int t = 0; t < neta; ++t) acc = fma(s_up[t], W[(long long)t * ldw + r], acc);
     v[r] = base - acc;
@@ -332,8 +330,7 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
                                                      double *xbar, double *z, double *zbar,
                                                      const double *__restrict__ dx,
                                                      const double *__restrict__ dz, int m, int q,
-                                                     const int *__restrict__ nonbasis,
-                                                     const int *__restrict__ var_col, int col0,
+                                                     const int *__restrict__ nbcode, int col0,
                                                      int col1, int sharded, double *fpx_r,
                                                      int *fpx_k, double *fpx_h, double *fpz_r,
                                                      int *fpz_k, double *fpz_h,
@@ -408,7 +405,7 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
         }
         bool mine = true; // sharded: z is only maintained for slack positions and owned columns
         if (sharded) {
-            const int code = var_col[nonbasis[k]];
+            const int code = nbcode[k];
             mine = code < 0 || (code >= col0 && code < col1);
         }
         if (mine && zb > 0.0) {
@@ -569,7 +566,7 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
 template <int MODE>
 __global__ __launch_bounds__(256) void k_shard_propose(
     const DzgCtl *ctl, int m, const double *__restrict__ A, long long lda, int col0, int col1,
-    const int *__restrict__ nonbasis, const int *__restrict__ var_col,
+    const int *__restrict__ nbcode,
     const double *__restrict__ z, const double *__restrict__ zbar, const double *__restrict__ dz,
     const double *__restrict__ pr, const int *__restrict__ pk, const double *__restrict__ ph,
     int np, double *__restrict__ rec, int csc, int hdr_only)
@@ -591,7 +588,7 @@ __global__ __launch_bounds__(256) void k_shard_propose(
         ratio = c.r;
         runner = c.h;
     }
-    const int code = pos >= 0 ? var_col[nonbasis[pos]] : -1;
+    const int code = pos >= 0 ? nbcode[pos] : -1;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             rec[0] = ratio;
@@ -649,7 +646,7 @@ void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const doubl
 {
     // mode 0: status + primal prep          1: dual ratio test + prep          (one GPU)
     //      4: merge proposals + status + primal prep     5: merge second exchange + dual prep
-#define SEL_ARGS d.ctl, d.m, d.A, d.lda, d.col0, xrecv, d.xstride, d.nonbasis, d.var_col,                \
+#define SEL_ARGS d.ctl, d.m, d.A, d.lda, d.col0, xrecv, d.xstride, d.nbcode,                            \
                        d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.rz_r, d.rz_k, d.rz_h, nrz,  \
                        d.W, d.ldw, d.drow, d.ag, d.beta, d.eps, d.world
     const dim3 grid(R_ + 1), block(256);
@@ -668,7 +665,7 @@ void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, h
 {
     const DzgPivotArgs pa = dzg_pivot_args(d);
 #define GEMV_ARGS d.ctl, need_kind, d.m, d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.col0, xrecv,  \
-                  d.xstride, d.basis, d.nonbasis, d.var_col, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h, pa
+                  d.xstride, d.bcode, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h, pa
     if (need_kind == DZG_STEP_DUAL)
         hipLaunchKernelGGL((k_fast_gemv<true>), dim3(DZG_NB_GEMV), dim3(256), 0, st, GEMV_ARGS);
     else
@@ -679,14 +676,14 @@ void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, h
 void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_btran, dim3((d.m + 255) / 256), dim3(256), 0, st, d.ctl, d.m, d.binv,
-                       d.ldb, d.dslot, d.basis, d.var_col, d.U, d.ldw, d.W, d.ldw, d.rx_r, d.rx_k, d.rx_h,
+                       d.ldb, d.dslot, d.bcode, d.U, d.ldw, d.W, d.ldw, d.rx_r, d.rx_k, d.rx_h,
                        d.v);
 }
 
 void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
-                       d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.nonbasis, d.var_col, d.col0, d.col1,
+                       d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.nbcode, d.col0, d.col1,
                        d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.v, d.U,
                        d.ldw, d.W, d.ldw, d.binv, d.ldb);
 }
@@ -707,11 +704,11 @@ void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend,
     const dim3 grid(hdr_only ? 1 : 1 + (d.m + 255) / 256);
     if (mode == 0)
         hipLaunchKernelGGL((k_shard_propose<0>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
-                           d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.fpz_r,
+                           d.col0, d.col1, d.nbcode, d.z, d.zbar, d.dz, d.fpz_r,
                            d.fpz_k, d.fpz_h, DZG_NB_UPD, xsend, d.csc, hdr_only);
     else
         hipLaunchKernelGGL((k_shard_propose<1>), grid, dim3(256), 0, st, d.ctl, d.m, d.A, d.lda,
-                           d.col0, d.col1, d.nonbasis, d.var_col, d.z, d.zbar, d.dz, d.rz_r, d.rz_k,
+                           d.col0, d.col1, d.nbcode, d.z, d.zbar, d.dz, d.rz_r, d.rz_k,
                            d.rz_h, nrz, xsend, d.csc, hdr_only);
     if (d.csc)
         hipLaunchKernelGGL(k_shard_scatter_col, dim3(1), dim3(256), 0, st, d.ctl, mode, d.cptr,
