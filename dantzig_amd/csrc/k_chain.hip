@@ -12,14 +12,18 @@
 //   * Every decision is taken by EVERY workgroup from the same partial results (a few KB), so a
 //     decision needs no broadcast; the lead lane of workgroup 0 only records it in the control
 //     block for the launches that follow.
-//   * A workgroup owns the same rows in FTRAN and in the update, and the same columns of z; the six
-//     values the step lengths need are read before any workgroup can have rewritten them (a dual
-//     step), or were left in the control block by k_chain_pre (a primal step).  The update
-//     therefore starts without waiting for anybody.
+//   * A workgroup owns the same rows in FTRAN, BTRAN and the update and the same columns of z, and
+//     nothing it reads inside a launch is rewritten by another workgroup of that launch: the six
+//     values the step lengths need are read before any writer can have got there (a dual step) or
+//     were left in the control block by k_chain_pre (a primal step); dx_p is computed by every
+//     workgroup itself, with the owner's arithmetic; Binv0's rows are read BEFORE the barrier beta
+//     is waited for (the eta file's share is added after it), so the column a deleting pivot moves
+//     is no longer read by anybody.  The update therefore starts without waiting for anybody, and
+//     the pivot's books are kept by ONE WAVE of workgroup 0 beside it.
 //
-//   What remains: the eta file's beta = W^T a_j must be complete before FTRAN's rows (1 barrier), a
-//   primal step's ratio test needs every row of dx (1 more), a compact column that is deleted must
-//   not be read any more (1, entering slacks only).  Barriers per iteration: 2 (primal), 1 (dual).
+//   What remains: the eta file's beta = W^T a_j must be complete before the eta share of FTRAN's
+//   rows (1 barrier), a primal step's ratio test needs every row of dx (1 more).
+//   Barriers per iteration: 2 (primal step: both in k_chain_pre), 1 (dual step: in k_chain_post).
 //
 // The barrier itself is fence-free (profiles/r02_gridsync_vs_kernel_boundary.txt): an agent-scope
 // release would write back the XCD's whole L2.  What crosses a barrier -- 64 doubles of beta, one
@@ -28,8 +32,10 @@
 // by the reading workgroup itself.  Arrivals are counted on eight counters (one per residue of the
 // workgroup index mod 8, so that 256 atomics do not queue on one address), the last arrival of a
 // residue class bumps the top counter everybody polls.  The counters only grow; the number of
-// barriers passed so far lives in the control block (bar_gen).  A poll loop gives up after ~1 s and
-// ends the solve with DZG_PANIC: every wave reaches its exit whatever happens.
+// barriers passed so far lives in the control block (bar_gen).  A poll loop gives up after ~1 s, marks
+// the control block (status DZG_PANIC, bar_timeout) and the host returns DZG_E_DEVICE: every wave
+// reaches its exit whatever happens (a barrier can only fail when the launch's workgroups are not
+// all resident, i.e. when something else occupies CUs or LDS of this device).
 //
 // Arithmetic: the row, dot-product, book-keeping and update formulas are the functions the
 // seven-launch kernels call (fast_rows.h), and argmax reductions do not depend on how candidates are

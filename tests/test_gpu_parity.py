@@ -893,3 +893,16 @@ def test_chain_hands_over_to_seven_launches_when_the_inverse_outgrows_lds(core, 
     assert r7.dense_columns > 24  # the cap was crossed
     want = ora.simplex_solve(ora.stdform_from_dense(np.array(a), b, c), max_iter=100000)
     assert log3(r3.pivots) == log3(want.pivots) and r3.status == want.status
+
+
+def test_chain_and_seven_launches_agree_over_a_whole_solve_of_config_2(core):
+    """BASELINE config 2 (1024 x 2048, seed 1002) solved to optimality in both forms: some 21 600
+    pivots, the compact inverse beyond 512 columns for most of them (the one-wave-per-row FTRAN), an
+    eta flush every 64 pivots -- same pivot log, margins, monitor and vectors, bit for bit."""
+    a, b, c = core.gen_dense_lp(seed=1002, m=1024, n_struct=2048)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    r3 = core.solve(lp, numerics=core.FAST, log_capacity=1 << 15)
+    r7 = core.solve(lp, numerics=core.FAST, log_capacity=1 << 15, seven_launches=1)
+    assert r3.status == "optimal" and r3.iterations > 20000 and r3.dense_columns > 512
+    assert _same_solution(r3, r7)
+    assert r3.objective == r7.objective
