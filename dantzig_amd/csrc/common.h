@@ -326,6 +326,7 @@ struct DzgDev {
     double *beta;      // [DZG_RMAX] W_t . a_j
     int *plist;        // [q] nonbasic positions holding structural variables (first nb_struct)
     int *pslot;        // [q] index into plist or -1
+    int *pcode;        // [q] column code of the variable at plist[i] (the pricing waves' column list)
     double *fpx_r, *fpz_r, *rx_r, *rz_r; // partial candidates (ratios)
     int *fpx_k, *fpz_k, *rx_k, *rz_k;    // partial candidates (positions)
     double *fpx_h, *fpz_h, *rx_h, *rz_h; // partial candidates (runner-up ratios, DzgCand2::h)

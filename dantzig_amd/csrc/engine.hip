@@ -554,6 +554,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.ag, (size_t)m + 2)); TRY(dev_alloc(s, &d.beta, (size_t)DZG_RMAX));
         TRY(dev_alloc(s, &d.plist, (size_t)q)); TRY(dev_alloc(s, &d.pslot, (size_t)q));
         TRY(dev_alloc(s, &d.bcode, (size_t)m)); TRY(dev_alloc(s, &d.nbcode, (size_t)q));
+        TRY(dev_alloc(s, &d.pcode, (size_t)q));
         const size_t np = 4096;
         TRY(dev_alloc(s, &d.fpx_r, np)); TRY(dev_alloc(s, &d.fpz_r, np));
         TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));

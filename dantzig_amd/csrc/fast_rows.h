@@ -156,7 +156,7 @@ struct DzgPivotArgs {
     int *drow, *dslot;
     double *W;
     long long ldw;
-    int *plist, *pslot;
+    int *plist, *pslot, *pcode;
     int col0, col1;
     const long long *cptr;
     int *log_kind, *log_enter, *log_leave;
@@ -172,7 +172,7 @@ inline DzgPivotArgs dzg_pivot_args(const DzgDev &d)
     pa.basis = d.basis; pa.nonbasis = d.nonbasis; pa.var_col = d.var_col;
     pa.bcode = d.bcode; pa.nbcode = d.nbcode;
     pa.binv = d.binv; pa.ldb = d.ldb; pa.drow = d.drow; pa.dslot = d.dslot;
-    pa.W = d.W; pa.ldw = d.ldw; pa.plist = d.plist; pa.pslot = d.pslot;
+    pa.W = d.W; pa.ldw = d.ldw; pa.plist = d.plist; pa.pslot = d.pslot; pa.pcode = d.pcode;
     pa.col0 = d.col0; pa.col1 = d.col1; pa.cptr = d.csc ? d.cptr : nullptr;
     pa.log_kind = d.log_kind; pa.log_enter = d.log_enter; pa.log_leave = d.log_leave;
     pa.log_mu = d.log_mu; pa.log_margin = d.log_margin; pa.log_cap = d.log_cap;
@@ -234,13 +234,14 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
     const int p = c.leave_pos, r = c.enter_pos, neta = c.neta;
     const long long s0 = c.nb_struct;
     // everything addressed by p, r -- issued together, used below
-    int vi = 0, vj = 0, idx_r = 0, lastpos = 0;
+    int vi = 0, vj = 0, idx_r = 0, lastpos = 0, lastcode = 0;
     const double max_err = ps.max_err;
     if (tid == 0) {
         vi = basis[p];
         vj = nonbasis[r];
         idx_r = pslot[r];
         lastpos = s0 > 0 ? plist[s0 - 1] : 0;
+        lastcode = s0 > 0 ? pa.pcode[s0 - 1] : 0;
         const int ci = var_col[vi], cj = var_col[vj]; // the two column codes
         if (ps.ok) {
             ctl->t = ps.t;
@@ -337,13 +338,17 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
     }
     if (own_j && !own_i) { // an owned structural column left the nonbasic set
         plist[idx_r] = lastpos;
+        pa.pcode[idx_r] = lastcode;
         pslot[lastpos] = idx_r;
         pslot[r] = -1;
         --s;
     } else if (!own_j && own_i) {
         plist[s] = r;
+        pa.pcode[s] = ci;
         pslot[r] = (int)s;
         ++s;
+    } else if (own_j && own_i) { // position r stays in the list with another column
+        pa.pcode[idx_r] = ci;
     }
     ctl->nb_struct = s;
     ctl->enter_var = vj;

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
                                                    int *pslot, int col0, int col1,
                                                    const long long *__restrict__ cptr, int *drow,
                                                    const int *__restrict__ basis, int *bcode,
-                                                   int *nbcode)
+                                                   int *nbcode, int *pcode)
 {
     // single workgroup: the structural-position list must be built in position order
     for (int r = threadIdx.x; r < m; r += blockDim.x) {
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
             const int code = var_col[nonbasis[k]];
             if (code >= col0 && code < col1) {
                 plist[s] = k;
+                pcode[s] = code;
                 pslot[k] = s;
                 ++s;
             } else {
@@ -638,7 +639,7 @@ void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
     hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
     hipLaunchKernelGGL(k_fast_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.dslot, d.nonbasis,
                        d.var_col, d.plist, d.pslot, d.col0, d.col1, d.csc ? d.cptr : nullptr, d.drow,
-                       d.basis, d.bcode, d.nbcode);
+                       d.basis, d.bcode, d.nbcode, d.pcode);
 }
 
 void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,

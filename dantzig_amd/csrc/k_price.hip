@@ -13,30 +13,30 @@ static int resolve(int kernel)
 static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
                         const int *plist, const int *nonbasis, const int *var_col, const double *v,
                         double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
-                        double *rz_h, int col0, hipStream_t st)
+                        double *rz_h, int col0, const int *pcode, hipStream_t st)
 {
     const dim3 grid(DZG_PRICE_TREE_BLOCKS), block(256);
     const int per_wave = (ncols + 4 * DZG_PRICE_TREE_BLOCKS - 1) / (4 * DZG_PRICE_TREE_BLOCKS);
     if (per_wave > 8)
-        hipLaunchKernelGGL((k_price_tree<16, 2>), grid, block, 0, st, PRICE_ARGS);
+        hipLaunchKernelGGL((k_price_tree<16, 2>), grid, block, 0, st, PRICE_ARGS, pcode);
     else if (per_wave > 4)
-        hipLaunchKernelGGL((k_price_tree<8, 4>), grid, block, 0, st, PRICE_ARGS);
+        hipLaunchKernelGGL((k_price_tree<8, 4>), grid, block, 0, st, PRICE_ARGS, pcode);
     else if (per_wave > 2)
-        hipLaunchKernelGGL((k_price_tree<4, 8>), grid, block, 0, st, PRICE_ARGS);
+        hipLaunchKernelGGL((k_price_tree<4, 8>), grid, block, 0, st, PRICE_ARGS, pcode);
     else if (per_wave > 1)
-        hipLaunchKernelGGL((k_price_tree<2, 16>), grid, block, 0, st, PRICE_ARGS);
+        hipLaunchKernelGGL((k_price_tree<2, 16>), grid, block, 0, st, PRICE_ARGS, pcode);
     else
-        hipLaunchKernelGGL((k_price_tree<1, 32>), grid, block, 0, st, PRICE_ARGS);
+        hipLaunchKernelGGL((k_price_tree<1, 32>), grid, block, 0, st, PRICE_ARGS, pcode);
 }
 
 static void launch(int kernel, int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
                    const int *plist, const int *nonbasis, const int *var_col, const double *v,
                    double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
-                   double *rz_h, int col0, hipStream_t st)
+                   double *rz_h, int col0, const int *pcode, hipStream_t st)
 {
     if (q <= 0) return;
     if (resolve(kernel) == DZG_PRICE_TREE)
-        launch_tree(ncols, PRICE_ARGS, st);
+        launch_tree(ncols, PRICE_ARGS, pcode, st);
     else if (resolve(kernel) == DZG_PRICE_WAVE)
         hipLaunchKernelGGL((k_price_wave2<4>), dim3(DZG_PRICE_WAVE_BLOCKS), dim3(256), 0, st, ctl, A,
                            lda, m, q, plist, nonbasis, var_col, v, dz, z, zbar, rz_r, rz_k, rz_h, col0);
@@ -84,7 +84,7 @@ void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
         return;
     }
     launch(kernel, d.q, d.ctl, d.A, d.lda, d.m, d.q, nullptr, d.nonbasis, d.var_col, d.v, d.dz, nullptr,
-           nullptr, nullptr, nullptr, nullptr, 0, st);
+           nullptr, nullptr, nullptr, nullptr, 0, nullptr, st);
 }
 
 // FAST numerics: structural positions from plist, ratio-test partials for the dual step
@@ -96,15 +96,16 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
     }
     // (column codes per nonbasic position, kept by the pivot's books: one load instead of
     // nonbasis[] -> var_col[] before a wave knows where its columns are)
+    // pcode[i] = code of the column at plist[i]: a wave learns its columns in one trip
     launch(kernel, d.col1 - d.col0, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nbcode, nullptr, d.v, d.dz, d.z,
-           d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, st);
+           d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, d.pcode, st);
 }
 
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st)
 {
     launch(kernel, ncols, nullptr, A, lda, m, ncols, nullptr, cols, nullptr, v, out, nullptr, nullptr,
-           nullptr, nullptr, nullptr, 0, st);
+           nullptr, nullptr, nullptr, 0, nullptr, st);
 }
 
 // CSC twin of dzg_launch_price_raw: cols[k] >= 0 is a stored column, < 0 the unit column of row

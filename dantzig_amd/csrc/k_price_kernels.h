@@ -54,6 +54,20 @@ __device__ __forceinline__ void price_candidate(DzgCand2 &best, double dzk, int 
     if (dzg_noise_zero(den, zk, scaled, tau)) best.h = __builtin_inf();
 }
 
+// the same with z[pos], zbar[pos] already in registers
+__device__ __forceinline__ void price_candidate_v(DzgCand2 &best, double dzk, int pos, double mu,
+                                                  double tau, double zk, double zbk)
+{
+    const double scaled = mu * zbk;
+    const double den = zk + scaled;
+    DzgCand2 c;
+    c.r = dzg_div(dzk, den);
+    c.k = pos;
+    c.h = -__builtin_inf();
+    if (c.r > 0.0) best = dzg_better2(best, c);
+    if (dzg_noise_zero(den, zk, scaled, tau)) best.h = __builtin_inf();
+}
+
 // unit columns: every thread of the grid takes positions pos = tid, tid + nthreads, ...
 __device__ __forceinline__ void price_slack_positions(DzgCand2 &best, int q,
                                                       const int *__restrict__ nonbasis,
@@ -359,7 +373,8 @@ __global__ __launch_bounds__(256) void k_price_tree(
     const int *__restrict__ plist, const int *__restrict__ nonbasis,
     const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
-    int *__restrict__ rz_k, double *__restrict__ rz_h, int col0 = 0)
+    int *__restrict__ rz_k, double *__restrict__ rz_h, int col0 = 0,
+    const int *__restrict__ pcode = nullptr)
 {
     constexpr int TR = 128;
     if (ctl && ctl->status != DZG_RUNNING) return;
@@ -368,7 +383,17 @@ __global__ __launch_bounds__(256) void k_price_tree(
     const int wg = blockIdx.x * 4 + wave;
     const double mu = ctl ? ctl->mu : 0.0, tau = ctl ? ctl->tau : 0.0;
     DzgCand2 best = dzg_cand2_none();
-    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, tau, z, zbar);
+    // The unit column of this thread's first position (pos = thread index): its code is fetched
+    // here, beside the wave's column list, its v / z / zbar entries beside the first matrix tiles,
+    // and the candidate is formed at the very end -- after a kernel boundary each of these is a
+    // trip to memory, and taken one behind the other (as price_slack_positions would) they would
+    // delay the first byte of the stream by several microseconds.
+    const int nthreads = gridDim.x * blockDim.x;
+    const int spos = blockIdx.x * blockDim.x + threadIdx.x;
+    int scode = 0; // >= 0: not a unit column
+    if (spos < q) scode = price_code(nonbasis, var_col, spos);
+    double sv = 0.0, sz = 0.0, szb = 0.0;
+    bool slack_loaded = false;
 
     const int count = plist ? (int)ctl->nb_struct : q;
     const int base = count / nw, rem = count % nw;
@@ -384,7 +409,7 @@ __global__ __launch_bounds__(256) void k_price_tree(
         if (lane < nc) {
             const int idx = start + c0 + lane;
             mypos = plist ? plist[idx] : idx;
-            mycode = price_code(nonbasis, var_col, mypos);
+            mycode = pcode ? pcode[idx] : price_code(nonbasis, var_col, mypos);
         }
         // wave-uniform column offsets; every load is unconditional (columns past nc and unit
         // columns re-read the wave's last valid column and are ignored), see k_price_seq2
@@ -404,6 +429,22 @@ __global__ __launch_bounds__(256) void k_price_tree(
         double acc[CW];
 #pragma unroll
         for (int l = 0; l < CW; ++l) acc[l] = 0.0;
+        // second trip, beside the first tiles: z, zbar of this lane's column; the unit column's data
+        double zc = 0.0, zbc = 0.0;
+        if (z && lane < nc && mycode >= 0) {
+            zc = z[mypos];
+            zbc = zbar[mypos];
+        }
+        if (!slack_loaded) {
+            slack_loaded = true;
+            if (scode < 0) {
+                sv = v[-1 - scode];
+                if (z) {
+                    sz = z[spos];
+                    szb = zbar[spos];
+                }
+            }
+        }
 
         auto fetch = [&](int t, double2_t(&reg)[CW], double2_t &vreg) {
             const int row = t * TR + 2 * lane;
@@ -455,7 +496,30 @@ __global__ __launch_bounds__(256) void k_price_tree(
         }
         if (lane < nc && mycode >= 0) {
             dz[mypos] = -mine;
-            if (z) price_candidate(best, -mine, mypos, mu, tau, z, zbar);
+            if (z) price_candidate_v(best, -mine, mypos, mu, tau, zc, zbc);
+        }
+    }
+    // ---- unit columns (the arithmetic of price_slack_positions)
+    if (scode < 0) {
+        if (!slack_loaded) { // (a wave without columns)
+            sv = v[-1 - scode];
+            if (z) {
+                sz = z[spos];
+                szb = zbar[spos];
+            }
+        }
+        const double p = 1.0 * -sv;
+        const double d = 0.0 + p; // Iterator::sum identity + the single stored entry
+        dz[spos] = d;
+        if (z) price_candidate_v(best, d, spos, mu, tau, sz, szb);
+    }
+    for (int pos = spos + nthreads; pos < q; pos += nthreads) { // more positions than threads
+        const int code = price_code(nonbasis, var_col, pos);
+        if (code < 0) {
+            const double p = 1.0 * -v[-1 - code];
+            const double d = 0.0 + p;
+            dz[pos] = d;
+            if (z) price_candidate(best, d, pos, mu, tau, z, zbar);
         }
     }
     price_publish(best, rz_r, rz_k, rz_h);
