@@ -225,7 +225,14 @@ def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
         solver.run(256)
         rc = solver.result(log=False)
         n = max(rc.iterations - rb.iterations, 1)
-        if rc.kernel_launches["status"] > rb.kernel_launches["status"]:
+        if rc.kernel_launches["ratio"] > rb.kernel_launches["ratio"] and \
+                rc.kernel_launches["status"] == rb.kernel_launches["status"]:
+            # the sparse-basis path (csrc/k_sparse.hip): status() is the head of the FTRAN launch
+            names = {"ftran": "status + primal FTRAN (k_sp_ftran_s<0>, k_sp_ftran_l)",
+                     "btran": "BTRAN row", "price": "pricing",
+                     "ratio": "dual ratio test + FTRAN (k_sp_ftran_s<1>, k_sp_ftran_l)",
+                     "update": "pivot + update", "basis_update": "eta flush (amortised)"}
+        elif rc.kernel_launches["status"] > rb.kernel_launches["status"]:
             names = {"status": "status + primal FTRAN prep", "ftran": "FTRAN GEMV (primal)",
                      "btran": "BTRAN row", "price": "pricing",
                      "ratio": "dual ratio + prep + FTRAN GEMV", "update": "pivot + update",

@@ -67,9 +67,10 @@ static void launch_csc(const DzgDev &d, const int *plist, const double *z, const
     // FAST (ratio test fused: z != nullptr) sums in tree order unless the caller insists on the
     // reference's order; STRICT always takes the reference's order
     if (z && !seq_order)
+        // (column codes per position / per list entry, kept by the pivot's books: one trip each)
         hipLaunchKernelGGL(k_price_csc_tree, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl,
-                           d.cptr, d.ridx, d.cval, d.q, plist, d.nonbasis, d.var_col, d.v, d.dz, z,
-                           zbar, rz_r, rz_k, rz_h, d.col0);
+                           d.cptr, d.ridx, d.cval, d.q, plist, d.nbcode, (const int *)nullptr, d.v,
+                           d.dz, z, zbar, rz_r, rz_k, rz_h, d.col0, plist ? d.pcode : (const int *)nullptr);
     else
         hipLaunchKernelGGL(k_price_csc, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl, d.cptr,
                            d.ridx, d.cval, d.q, plist, d.nonbasis, d.var_col, d.v, d.dz, z, zbar,

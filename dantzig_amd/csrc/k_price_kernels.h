@@ -607,12 +607,19 @@ __global__ __launch_bounds__(256) void k_price_csc_tree(
     const int *__restrict__ nonbasis, const int *__restrict__ var_col,
     const double *__restrict__ v, double *__restrict__ dz, const double *__restrict__ z,
     const double *__restrict__ zbar, double *__restrict__ rz_r, int *__restrict__ rz_k,
-    double *__restrict__ rz_h, int col0)
+    double *__restrict__ rz_h, int col0, const int *__restrict__ pcode = nullptr)
 {
     if (ctl && ctl->status != DZG_RUNNING) return;
     const double mu = ctl ? ctl->mu : 0.0, tau = ctl ? ctl->tau : 0.0;
     DzgCand2 best = dzg_cand2_none();
-    price_slack_positions(best, q, nonbasis, var_col, v, dz, mu, tau, z, zbar);
+    // the unit column of this thread's first position: fetched beside the column work, used at the
+    // end (see k_price_tree)
+    const int nthreads = gridDim.x * blockDim.x;
+    const int spos = blockIdx.x * blockDim.x + threadIdx.x;
+    int scode = 0;
+    if (spos < q) scode = price_code(nonbasis, var_col, spos);
+    double sv = 0.0, sz = 0.0, szb = 0.0;
+    bool slack_loaded = false;
     const int count = plist ? (int)ctl->nb_struct : q;
     const int sub = threadIdx.x & 7;
     const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
@@ -623,10 +630,25 @@ __global__ __launch_bounds__(256) void k_price_csc_tree(
         long long e0 = 0, e1 = 0;
         if (idx < count) {
             pos = plist ? plist[idx] : idx;
-            code = price_code(nonbasis, var_col, pos);
+            code = pcode ? pcode[idx] : price_code(nonbasis, var_col, pos);
             if (code >= 0) {
                 e0 = cptr[code - col0];
                 e1 = cptr[code - col0 + 1];
+            }
+        }
+        double zc = 0.0, zbc = 0.0;
+        if (z && code >= 0 && sub == 0) {
+            zc = z[pos];
+            zbc = zbar[pos];
+        }
+        if (!slack_loaded) {
+            slack_loaded = true;
+            if (scode < 0) {
+                sv = v[-1 - scode];
+                if (z) {
+                    sz = z[spos];
+                    szb = zbar[spos];
+                }
             }
         }
         double a0 = 0.0, a1 = 0.0; // two independent chains per lane
@@ -643,7 +665,30 @@ __global__ __launch_bounds__(256) void k_price_csc_tree(
         for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
         if (code >= 0 && sub == 0) {
             dz[pos] = -acc;
-            if (z) price_candidate(best, -acc, pos, mu, tau, z, zbar);
+            if (z) price_candidate_v(best, -acc, pos, mu, tau, zc, zbc);
+        }
+    }
+    // ---- unit columns (the arithmetic of price_slack_positions)
+    if (scode < 0) {
+        if (!slack_loaded) {
+            sv = v[-1 - scode];
+            if (z) {
+                sz = z[spos];
+                szb = zbar[spos];
+            }
+        }
+        const double p = 1.0 * -sv;
+        const double d = 0.0 + p; // Iterator::sum identity + the single stored entry
+        dz[spos] = d;
+        if (z) price_candidate_v(best, d, spos, mu, tau, sz, szb);
+    }
+    for (int pos = spos + nthreads; pos < q; pos += nthreads) { // more positions than threads
+        const int code = price_code(nonbasis, var_col, pos);
+        if (code < 0) {
+            const double p = 1.0 * -v[-1 - code];
+            const double d = 0.0 + p;
+            dz[pos] = d;
+            if (z) price_candidate(best, d, pos, mu, tau, z, zbar);
         }
     }
     price_publish(best, rz_r, rz_k, rz_h);

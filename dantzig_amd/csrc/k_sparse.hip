@@ -66,8 +66,8 @@ __device__ __forceinline__ double sp_block_sum(double x)
 template <int KIND>
 __global__ __launch_bounds__(256) void k_sp_ftran_s(
     DzgCtl *ctl, int m, const long long *__restrict__ cptr, const int *__restrict__ ridx,
-    const double *__restrict__ cval, const int *__restrict__ nonbasis,
-    const int *__restrict__ var_col, const double *__restrict__ fpx_r,
+    const double *__restrict__ cval, const int *__restrict__ nbcode,
+    const double *__restrict__ fpx_r,
     const int *__restrict__ fpx_k, const double *__restrict__ fpx_h,
     const double *__restrict__ fpz_r, const int *__restrict__ fpz_k,
     const double *__restrict__ fpz_h, const double *__restrict__ rz_r,
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
         mu = c.mu;
         if (lead) ctl->enter_pos = epos;
     }
-    const int code = var_col[nonbasis[epos]];
+    const int code = nbcode[epos];
     if (lead) ctl->enter_code = code;
     const int k = c.ncompact, neta = c.neta;
     const double tau = c.tau;
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void k_sp_ftran_l(
 __global__ __launch_bounds__(256) void k_sp_btran(
     DzgCtl *ctl, int m, int nparts, const long long *__restrict__ rptr,
     const int *__restrict__ bcnt, const int *__restrict__ bcol, const double *__restrict__ bval,
-    const int *__restrict__ bslot, const int *__restrict__ sslot, const int *__restrict__ basis,
-    const int *__restrict__ var_col, const double *__restrict__ X, long long ldb,
+    const int *__restrict__ bslot, const int *__restrict__ sslot, const int *__restrict__ bcode,
+    const double *__restrict__ X, long long ldb,
     const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
     const int *__restrict__ drow, const int *__restrict__ dslot,
     const double *__restrict__ rx_r, const int *__restrict__ rx_k,
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     }
     const int k = c.ncompact, neta = c.neta;
     const int bp = sslot[p];
-    const int rl = bp >= 0 ? -1 : -1 - var_col[basis[p]]; // row whose slack is basic at p
+    const int rl = bp >= 0 ? -1 : -1 - bcode[p]; // row whose slack is basic at p
     const int tid = threadIdx.x, stride = gridDim.x * blockDim.x;
     const int gid = blockIdx.x * blockDim.x + tid;
     // rows outside R: zero, except the leaving slack's own row
@@ -354,7 +354,7 @@ __device__ __forceinline__ int sp_pivot_books(
     const double *__restrict__ dz, int *basis, int *nonbasis, const int *__restrict__ var_col,
     int *drow, int *dslot, int *sslot, int *spos, int *bslot, int *rowpos, int *plist, int *pslot,
     const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
-    double *log_mu, double *log_margin, long long log_cap)
+    double *log_mu, double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode)
 {
     const double xp = x[p], xbp = xbar[p], dxp = dx[p];
     const double zr = z[r], zbr = zbar[r], dzr = dz[r];
@@ -445,20 +445,26 @@ __device__ __forceinline__ int sp_pivot_books(
                        8.0 * (double)m + 32.0 * (double)q;
     basis[p] = vj;
     nonbasis[r] = vi;
+    bcode[p] = cj;
+    nbcode[r] = ci;
     long long nnz = c.nb_nnz;
     if (cj >= 0) nnz -= cptr[cj + 1] - cptr[cj];
     if (ci >= 0) nnz += cptr[ci + 1] - cptr[ci];
     ctl->nb_nnz = nnz;
     if (cj >= 0 && ci < 0) { // a structural column left the nonbasic set
-        const int idx = pslot[r], lastpos = plist[ns - 1];
+        const int idx = pslot[r], lastpos = plist[ns - 1], lastcode = pcode[ns - 1];
         plist[idx] = lastpos;
+        pcode[idx] = lastcode;
         pslot[lastpos] = idx;
         pslot[r] = -1;
         --ns;
     } else if (cj < 0 && ci >= 0) {
         plist[ns] = r;
+        pcode[ns] = ci;
         pslot[r] = (int)ns;
         ++ns;
+    } else if (cj >= 0 && ci >= 0) { // position r stays in the list with another column
+        pcode[pslot[r]] = ci;
     }
     ctl->nb_struct = ns;
     ctl->enter_var = vj;
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
     const long long *__restrict__ cptr, const int *__restrict__ ridx,
     const double *__restrict__ cval, const long long *__restrict__ rptr, int *bcnt, int *bcol,
     double *bval, int *log_kind, int *log_enter, int *log_leave, double *log_mu,
-    double *log_margin, long long log_cap)
+    double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode)
 {
     __shared__ int s_ok, s_ci, s_cj;
     const DzgCtl c = *ctl;
@@ -500,12 +506,12 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
     if (threadIdx.x == 0) { // one lane reads the pivot's variables BEFORE it swaps them
         const int p = c.leave_pos, r = c.enter_pos;
         const int vi = basis[p], vj = nonbasis[r];
-        s_ci = var_col[vi];
-        s_cj = var_col[vj];
+        s_ci = bcode[p]; // (= var_col[vi], in the same trip to memory as vi)
+        s_cj = nbcode[r];
         s_ok = sp_pivot_books(ctl, c, m, q, p, r, c.neta, vi, vj, s_ci, s_cj, x, xbar, z, zbar, dx, dz,
                               basis, nonbasis, var_col, drow, dslot, sslot, spos, bslot, rowpos,
                               plist, pslot, cptr, log_kind, log_enter, log_leave, log_mu,
-                              log_margin, log_cap);
+                              log_margin, log_cap, bcode, nbcode, pcode);
     }
     __syncthreads();
     if (!s_ok) return;
@@ -789,7 +795,7 @@ void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st)
 void dzg_launch_sp_ftran(const DzgDev &d, int need_kind, int nrz, hipStream_t st)
 {
     const int gs = sp_grid(d.m), gl = sp_grid(d.m);
-#define SP_FS_ARGS d.ctl, d.m, d.cptr, d.ridx, d.cval, d.nonbasis, d.var_col, d.fpx_r, d.fpx_k, d.fpx_h,  \
+#define SP_FS_ARGS d.ctl, d.m, d.cptr, d.ridx, d.cval, d.nbcode, d.fpx_r, d.fpx_k, d.fpx_h,              \
                    d.fpz_r, d.fpz_k, d.fpz_h, d.rz_r, d.rz_k, d.rz_h, nrz, d.binv, d.ldb, d.U, d.ldw, d.W,  \
                    d.ldw, d.dslot, d.spos, d.x, d.xbar, d.dxs, d.dx, d.rx_r, d.rx_k, d.rx_h, d.acol,        \
                    d.acol_code, d.eps
@@ -807,7 +813,7 @@ void dzg_launch_sp_btran(const DzgDev &d, hipStream_t st)
 {
     const int nparts = 2 * sp_grid(d.m);
     hipLaunchKernelGGL(k_sp_btran, dim3(sp_grid(d.m)), dim3(256), 0, st, d.ctl, d.m, nparts, d.rptr,
-                       d.bcnt, d.bcol, d.bval, d.bslot, d.sslot, d.basis, d.var_col, d.binv, d.ldb, d.U,
+                       d.bcnt, d.bcol, d.bval, d.bslot, d.sslot, d.bcode, d.binv, d.ldb, d.U,
                        d.ldw, d.W, d.ldw, d.drow, d.dslot, d.rx_r, d.rx_k, d.rx_h, d.v);
 }
 
@@ -817,7 +823,7 @@ void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st)
                        d.zbar, d.dx, d.dz, d.basis, d.nonbasis, d.var_col, d.drow, d.dslot, d.sslot,
                        d.spos, d.bslot, d.rowpos, d.plist, d.pslot, d.cptr, d.ridx, d.cval, d.rptr, d.bcnt,
                        d.bcol, d.bval, d.log_kind, d.log_enter, d.log_leave, d.log_mu, d.log_margin,
-                       d.log_cap);
+                       d.log_cap, d.bcode, d.nbcode, d.pcode);
 }
 
 void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st)
