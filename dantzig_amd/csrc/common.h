@@ -423,9 +423,10 @@ void dzg_launch_lockstep_allgather(double *const *ptrs, int world, int which, lo
 // k_chain.hip: the FAST iteration of the dense inverse in three launches (one GPU)
 #define DZG_CHAIN_AGCAP 16384 // compact width up to which the chain runs (the gathered column in LDS)
 void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
-                          unsigned long long *dbg, hipStream_t st);
+                          unsigned long long *dbg, const double *xrecv, hipStream_t st);
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
-                           unsigned long long *dbg, int only_partials, int nrz, hipStream_t st);
+                           unsigned long long *dbg, int only_partials, int nrz, const double *xrecv,
+                           hipStream_t st);
 
 // k_sparse.hip
 void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st);

@@ -570,7 +570,8 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             HIP_OK(hipMemsetAsync(d.acol, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
             HIP_OK(hipMemsetAsync(d.dxs, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
         }
-        if (d.world == 1 && !d.csc && !o.seven_launches) {
+        // one GPU, or a column-sharded rank that keeps the whole matrix (the entering column is local)
+        if ((d.world == 1 || d.repl) && !d.csc && !o.seven_launches) {
             // the chain's barriers need every workgroup resident at once: one per CU
             hipDeviceProp_t prop;
             HIP_OK(hipGetDeviceProperties(&prop, o.device));
@@ -705,13 +706,13 @@ static void enqueue_chain_iteration(dzg_solver *s, int slot)
     Prof pf{s, slot};
     const int pk = price_kernel_for(s);
     pf.begin(DZG_K_FTRAN);
-    dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, st); // status, primal FTRAN + ratio, BTRAN row
+    dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, nullptr, st); // status, primal FTRAN + ratio, BTRAN row
     pf.end(DZG_K_FTRAN);
     pf.begin(DZG_K_PRICE);
     dzg_launch_price_fast(d, pk, st);
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_UPDATE);
-    dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0, price_partials_for(s, pk), st);
+    dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0, price_partials_for(s, pk), nullptr, st);
     pf.end(DZG_K_UPDATE);
     pf.begin(DZG_K_BASIS_UPDATE);
     if (++s->since_flush >= DZG_RMAX) {
@@ -759,7 +760,8 @@ static void collect_profile(dzg_solver *s, int slots_real)
             if (!(s->opts.profile & (1 << cls))) continue;
             if (s->d.csc && !s->d.spb && s->d.world == 1 && !s->comm && cls != DZG_K_PRICE)
                 continue; // the single-GPU record path of a CSC solver only stamps pricing
-            if (s->batch_chain && (cls == DZG_K_STATUS || cls == DZG_K_BTRAN || cls == DZG_K_RATIO))
+            if (s->batch_chain && s->d.world == 1 && !s->comm &&
+                (cls == DZG_K_STATUS || cls == DZG_K_BTRAN || cls == DZG_K_RATIO))
                 continue; // the chain has no launches of their own for these
             float ms = 0.f;
             size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
@@ -1092,9 +1094,13 @@ extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *s
     hipStream_t st = s->st;
     const int pk = price_kernel_for(s);
     phase_stamp(s, DZG_K_FTRAN, 0);
-    dzg_launch_fast_select_prep(d, 4, 0, recv_dev, st);    // merge + status() + primal FTRAN prep
-    dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, recv_dev, st);
-    dzg_launch_fast_btran(d, st);
+    if (s->batch_chain) { // (replicated matrix) the three kernels below in one launch, k_chain.hip
+        dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, recv_dev, st);
+    } else {
+        dzg_launch_fast_select_prep(d, 4, 0, recv_dev, st);    // merge + status() + primal FTRAN prep
+        dzg_launch_fast_gemv(d, DZG_STEP_PRIMAL, recv_dev, st);
+        dzg_launch_fast_btran(d, st);
+    }
     phase_stamp(s, DZG_K_FTRAN, 1);
     phase_stamp(s, DZG_K_PRICE, 0);
     dzg_launch_price_fast(d, pk, st);                      // owned columns only
@@ -1111,9 +1117,13 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     phase_stamp(s, DZG_K_UPDATE, 0);
-    dzg_launch_fast_select_prep(d, 5, 0, recv_dev, st);    // merge + (dual) FTRAN prep
-    dzg_launch_fast_gemv(d, DZG_STEP_DUAL, recv_dev, st); // + the pivot's books
-    dzg_launch_fast_update(d, 0, st);
+    if (s->batch_chain) {
+        dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0, 0, recv_dev, st);
+    } else {
+        dzg_launch_fast_select_prep(d, 5, 0, recv_dev, st);    // merge + (dual) FTRAN prep
+        dzg_launch_fast_gemv(d, DZG_STEP_DUAL, recv_dev, st); // + the pivot's books
+        dzg_launch_fast_update(d, 0, st);
+    }
     if (++s->since_flush >= DZG_RMAX) {
         dzg_launch_fast_flush(d, st);
         s->since_flush = 0;
@@ -1198,6 +1208,7 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         const int batch = batch_size(s);
         s->since_flush = s->h_ctl->neta;
         s->since_refactor += batch;
+        s->batch_chain = s->chain_bar && (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
         for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
@@ -1215,6 +1226,10 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         s->prof_slot = -1;
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
+        if (s->h_ctl->bar_timeout)
+            return fail(DZG_E_DEVICE, "a device-wide barrier of the fused phase kernels timed out: their "
+                                      "workgroups were not all resident; opts.seven_launches = 1 runs "
+                                      "without barriers");
         collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
         bool stop = false;
@@ -1264,6 +1279,8 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         for (int r = 0; r < world; ++r) {
             sv[r]->since_flush = sv[r]->h_ctl->neta;
             sv[r]->since_refactor += batch;
+            sv[r]->batch_chain =
+                sv[r]->chain_bar && (long long)sv[r]->h_ctl->ncompact + batch <= sv[r]->chain_kcap;
         }
         for (int b = 0; b < batch; ++b) {
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));
@@ -1274,6 +1291,9 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         }
         for (int r = 0; r < world; ++r) TRY(read_ctl(sv[r]));
         HIP_OK(hipGetLastError());
+        for (int r = 0; r < world; ++r)
+            if (sv[r]->h_ctl->bar_timeout)
+                return fail(DZG_E_DEVICE, "lockstep: a device-wide barrier timed out");
         for (int r = 1; r < world; ++r)
             if (sv[r]->h_ctl->status != sv[0]->h_ctl->status || sv[r]->h_ctl->iter != sv[0]->h_ctl->iter)
                 return fail(DZG_E_DEVICE, "lockstep: ranks diverged");

@@ -24,6 +24,29 @@ __device__ __forceinline__ double block_sum(double x)
     return t;
 }
 
+// Merge of the ranks' proposals.  Slack positions are replicated, so several ranks may propose
+// the SAME position (with the same ratio): that is one candidate, not a tie.
+__device__ __forceinline__ int shard_merge(const double *__restrict__ xrecv, long long xstride,
+                                           int world, DzgCand2 &win)
+{
+    int w = -1;
+    win = dzg_cand2_none();
+    for (int r = 0; r < world; ++r) {
+        const double *rec = xrecv + (long long)r * xstride;
+        DzgCand2 c;
+        c.r = rec[0];
+        c.k = (int)rec[1];
+        c.h = rec[6]; // the rank's own runner-up (or hazard mark)
+        if (c.k < 0 || c.r != c.r || c.k == win.k) {
+            if (c.h > win.h) win.h = c.h;
+            continue;
+        }
+        win = dzg_better2(win, c);
+        if (win.k == c.k) w = r;
+    }
+    return w;
+}
+
 // beta_t = W_t . a_j by one workgroup (every thread calls; the first 256 threads carry the sum, in
 // an order that depends on m only: four strided partial sums per thread, a wave tree, the waves in
 // order -- further waves add +0.0, so workgroups of 256 and of 512 threads give the same bits)

@@ -292,8 +292,13 @@ __device__ __forceinline__ void chain_dot_tail(const DzgDev &d, int r0, int r1, 
 // k_chain_pre: src/simplex.rs:274-306 (status), :226-229 + :439-461 (a primal step's FTRAN and
 // ratio test), then v = row p of the inverse (:231-236's solve).  grid = one workgroup per CU.
 // ---------------------------------------------------------------------------------
+// SHARD (column sharding with the matrix replicated, one process per GPU): the z-side first pivot
+// comes from the merge of every rank's proposal (xrecv: the first exchange's records) -- all ranks
+// see the same records in the same order and apply the same rule, so they take the same decision.
+template <bool SHARD>
 __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsigned long long *bar,
-                                                          unsigned long long *dbg)
+                                                          unsigned long long *dbg,
+                                                          const double *__restrict__ xrecv)
 {
     __shared__ double s_ag[CH_AGCAP];
     __shared__ double s_beta[R_], s_dx[CH_THREADS];
@@ -306,10 +311,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
     const bool lead = blockIdx.x == 0 && tid == 0;
     // ---- first touches, side by side: candidates of the last update, this thread's row
     ChainSpec sp;
-    if (wave == 0)
+    if (wave == 0 && !SHARD)
         chain_spec_load(sp, d.fpz_r, d.fpz_k, d.fpz_h, lane);
     else if (wave == 1)
         chain_spec_load(sp, d.fpx_r, d.fpx_k, d.fpx_h, lane);
+    DzgCand2 cj_rec = dzg_cand2_none();
+    int w_rec = -1;
+    if (SHARD) w_rec = shard_merge(xrecv, d.xstride, d.world, cj_rec);
     int r0, r1;
     chain_rows(m, r0, r1);
     const int row = r0 + tid;
@@ -328,15 +336,15 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
     const int neta = c.neta, k = c.ncompact;
     const int dr0 = tid < k ? d.drow[tid] : -1;
     const int dr1 = tid + CH_THREADS < k ? d.drow[tid + CH_THREADS] : -1;
-    if (wave < 2) {
+    if (wave < 2 && !(SHARD && wave == 0)) {
         const DzgCand2 w = chain_spec_reduce(sp, c.fp_count, lane);
         if (lane == 0) chain_put(s_c, wave, w);
     }
     __syncthreads();
-    const DzgCand2 cj = chain_get(s_c, 0), ci = chain_get(s_c, 1);
+    const DzgCand2 cj = SHARD ? cj_rec : chain_get(s_c, 0), ci = chain_get(s_c, 1);
     int kind;
     double mu;
-    if (!fast_status(ctl, c, lead, cj, ci, d.eps, m, false, kind, &mu)) return;
+    if (!fast_status(ctl, c, lead, cj, ci, d.eps, m, SHARD, kind, &mu)) return;
     const int slot = kind == DZG_STEP_PRIMAL ? 0 : 1;
     ts.mark(slot); // 0: first touches + status
     if (k > CH_AGCAP || c.fp_count > 256) { // the host runs the seven launches before this can happen
@@ -367,9 +375,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
         chain_beta(d, neta, code, a);
         if (lead) {
             ctl->enter_code = code;
-            ctl->zr = zr;
-            ctl->zbar_r = zbr;
+            ctl->zr = zr; // (SHARD: z is kept by the column's owner; k_chain_post takes it from
+            ctl->zbar_r = zbr; //  the second exchange's records instead)
             ctl->enter_dslot = edslot;
+            if (SHARD) ctl->enter_src = w_rec;
         }
         __syncthreads(); // the gathered column is complete
         double accs[CH_MAXP];
@@ -457,9 +466,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
 // (:262-265, :410-421) with the eta append, and the first-pivot candidates of the next iteration
 // (:423-437).  only_partials != 0: the candidates only.
 // ---------------------------------------------------------------------------------
+// SHARD: the ratio test of a dual step is the merge of the ranks' proposals (xrecv: the second
+// exchange's records), z, zbar, dz of the entering position come from its owner's record, and z is
+// only kept -- and offered as a first-pivot candidate -- for slack positions and owned columns.
+template <bool SHARD>
 __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsigned long long *bar,
                                                            const DzgPivotArgs pa, int only_partials,
-                                                           int nrz, unsigned long long *dbg)
+                                                           int nrz, unsigned long long *dbg,
+                                                           const double *__restrict__ xrecv)
 {
     __shared__ double s_ag[CH_AGCAP];
     __shared__ double s_beta[R_], s_dx[CH_THREADS];
@@ -476,7 +490,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
     DzgCand2 mine = dzg_cand2_none();
     ChainSpec sp;
     const bool one_wave = nrz <= 256; // (block-uniform) the candidates fit one wave's registers
-    if (!only_partials && one_wave) {
+    if (SHARD) {
+        // (the candidates travel in the exchange records)
+    } else if (!only_partials && one_wave) {
         if (wave == 0) chain_spec_load(sp, d.rz_r, d.rz_k, d.rz_h, lane);
     } else if (!only_partials) {
 #pragma unroll
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
     const int row = r0 + tid, col = q0 + tid;
     const bool has_row = row < r1, has_col = col < q1;
     double x_i = 0.0, xbar_i = 0.0, v_i = 0.0, dx_i = 0.0, z_k = 0.0, zbar_k = 0.0, dz_k = 0.0;
-    int bcode_i = 0;
+    int bcode_i = 0, nbcode_k = -1;
     if (has_row) {
         x_i = d.x[row];
         xbar_i = d.xbar[row];
@@ -516,12 +532,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
         z_k = d.z[col];
         zbar_k = d.zbar[col];
         if (!only_partials) dz_k = d.dz[col];
+        if (SHARD) nbcode_k = d.nbcode[col]; // (before the books of this launch rewrite position r's)
     }
     DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     unsigned long long gen = c.bar_gen;
     // what the update needs (all block-uniform)
-    int p = 0, r = 0, teta = 0, wzero = -1, del_ce = -1, del_last = -1, app_col = -1;
+    int p = 0, r = 0, teta = 0, wzero = -1, del_ce = -1, del_last = -1, app_col = -1, new_code_r = -1;
     double t = 0.0, s = 0.0, tbar = 0.0, sbar = 0.0, rdxp = 0.0, tau = c.tau;
     if (!only_partials) {
         const int neta = c.neta_cur, k = c.k_cur, kind = c.kind;
@@ -534,7 +551,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             const int dr0 = tid < k ? d.drow[tid] : -1;
             const int dr1 = tid + CH_THREADS < k ? d.drow[tid + CH_THREADS] : -1;
             DzgCand2 cw;
-            if (one_wave) {
+            int w_rec = -1;
+            if (SHARD) {
+                w_rec = shard_merge(xrecv, d.xstride, d.world, cw);
+            } else if (one_wave) {
                 if (wave == 0) {
                     const DzgCand2 w = chain_spec_reduce(sp, nrz, lane);
                     if (lane == 0) chain_put(s_c, 0, w);
@@ -548,10 +568,25 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             slot = 3;
             ts.mark(slot); // 0: first touches + ratio test
             r = cw.k;
-            cj = d.nbcode[r];
-            zr = d.z[r];
-            zbr = d.zbar[r];
-            dzr = d.dz[r];
+            if (SHARD) { // the entering column's code and z, zbar, dz travel in the winner's record
+                const double *rec = xrecv + (long long)w_rec * d.xstride;
+                cj = (int)rec[5];
+                zr = rec[2];
+                zbr = rec[3];
+                dzr = rec[4];
+                if (lead) {
+                    ctl->enter_src = w_rec;
+                    ctl->zr = zr;
+                    ctl->zbar_r = zbr;
+                    ctl->dz_r = dzr;
+                    ctl->use_record = 1;
+                }
+            } else {
+                cj = d.nbcode[r];
+                zr = d.z[r];
+                zbr = d.zbar[r];
+                dzr = d.dz[r];
+            }
             const double *a = cj < 0 ? nullptr : d.A + (long long)(cj - d.col0) * d.lda;
             edslot = cj < 0 ? d.dslot[-1 - cj] : -1;
             const bool has_unit = has_row && bcode_i < 0;
@@ -613,12 +648,32 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             zr = c.zr;
             zbr = c.zbar_r;
             dzr = d.dz[r];
+            if (SHARD) { // the owner of the entering position has published z, zbar, dz
+                int w_rec = -1;
+                for (int rk = 0; rk < d.world && w_rec < 0; ++rk)
+                    if ((int)xrecv[(long long)rk * d.xstride + 1] == r) w_rec = rk;
+                if (w_rec < 0) { // no rank owns the entering position: cannot happen
+                    if (lead) ctl->status = DZG_PANIC;
+                    return;
+                }
+                const double *rec = xrecv + (long long)w_rec * d.xstride;
+                zr = rec[2];
+                zbr = rec[3];
+                dzr = rec[4];
+                if (lead) {
+                    ctl->zr = zr;
+                    ctl->zbar_r = zbr;
+                    ctl->dz_r = dzr;
+                    ctl->use_record = 1;
+                }
+            }
             edslot = c.enter_dslot;
             dxp = d.dx[p];
             ts.mark(slot); // 0: first touches
         }
         const DzgPivotScalars ps = fast_pivot_scalars(xp, xbp, dxp, zr, zbr, dzr, neta, c.max_pivot_err);
         const bool appended = ci < 0, deleted = cj < 0;
+        new_code_r = ci; // the leaving variable takes nonbasic position r
         if (blockIdx.x == 0 && wave == CH_NW - 1) { // one wave keeps the books
             c.neta = neta;
             c.ncompact = k;
@@ -689,14 +744,19 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             d.z[col] = zk;
             d.zbar[col] = zb;
         }
-        if (zb > 0.0) {
+        bool mine = true; // SHARD: z is only kept for slack positions and owned columns
+        if (SHARD) {
+            const int code = (!only_partials && col == r) ? new_code_r : nbcode_k;
+            mine = code < 0 || (code >= d.col0 && code < d.col1);
+        }
+        if (mine && zb > 0.0) {
             DzgCand2 cn;
             cn.r = dzg_div(-zk, zb);
             cn.k = col;
             cn.h = -inf;
             if (cn.r == cn.r) bz = dzg_better2(bz, cn);
         }
-        if (fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
+        if (mine && fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
     }
     bx = chain_best(bx, r1 - r0);
     bz = chain_best(bz, q1 - q0);
@@ -713,15 +773,24 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
     ts.done(slot);
 }
 
+// xrecv != nullptr: a column-sharded rank (replicated matrix), records of the exchange just done
 void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
-                          unsigned long long *dbg, hipStream_t st)
+                          unsigned long long *dbg, const double *xrecv, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_chain_pre, dim3(grid), dim3(CH_THREADS), 0, st, d, bar, dbg);
+    if (xrecv)
+        hipLaunchKernelGGL(k_chain_pre<true>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar, dbg, xrecv);
+    else
+        hipLaunchKernelGGL(k_chain_pre<false>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar, dbg, xrecv);
 }
 
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
-                           unsigned long long *dbg, int only_partials, int nrz, hipStream_t st)
+                           unsigned long long *dbg, int only_partials, int nrz, const double *xrecv,
+                           hipStream_t st)
 {
-    hipLaunchKernelGGL(k_chain_post, dim3(grid), dim3(CH_THREADS), 0, st, d, bar, dzg_pivot_args(d),
-                       only_partials, nrz, dbg);
+    if (xrecv)
+        hipLaunchKernelGGL(k_chain_post<true>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar,
+                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv);
+    else
+        hipLaunchKernelGGL(k_chain_post<false>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar,
+                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv);
 }

@@ -33,29 +33,6 @@
 #include "fast_decide.h"
 #include "fast_rows.h"
 
-// Merge of the ranks' proposals.  Slack positions are replicated, so several ranks may propose
-// the SAME position (with the same ratio): that is one candidate, not a tie.
-__device__ __forceinline__ int shard_merge(const double *__restrict__ xrecv, long long xstride,
-                                           int world, DzgCand2 &win)
-{
-    int w = -1;
-    win = dzg_cand2_none();
-    for (int r = 0; r < world; ++r) {
-        const double *rec = xrecv + (long long)r * xstride;
-        DzgCand2 c;
-        c.r = rec[0];
-        c.k = (int)rec[1];
-        c.h = rec[6]; // the rank's own runner-up (or hazard mark)
-        if (c.k < 0 || c.r != c.r || c.k == win.k) {
-            if (c.h > win.h) win.h = c.h;
-            continue;
-        }
-        win = dzg_better2(win, c);
-        if (win.k == c.k) w = r;
-    }
-    return w;
-}
-
 // ---------------------------------------------------------------------------------
 // k_fast_select_prep<MODE>
 //   MODE 0: head of the iteration.  status(): first pivots on both sides from the partials
@@ -584,7 +561,8 @@ __global__ __launch_bounds__(256) void k_shard_propose(
         }
         want_column = false; // FTRAN already happened
     } else {
-        const DzgCand2 c = reduce_partials(pr, pk, ph, np);
+        // MODE 0: as many first-pivot candidates as the last update left (its grid size)
+        const DzgCand2 c = reduce_partials(pr, pk, ph, MODE == 0 ? ctl->fp_count : np);
         pos = c.k;
         ratio = c.r;
         runner = c.h;
