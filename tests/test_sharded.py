@@ -215,19 +215,20 @@ def test_sharded_sparse_lockstep_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [4, 8])
-def test_sharded_whole_solve_follows_the_oracle_pivot_log(world):
-    """BASELINE config 2 (1024 x 2048) column-sharded over 4 / 8 ranks in lockstep on one GPU: every
-    rank takes the 21 642 pivots of the committed CPU-oracle log (tests/golden, 106 min of CPU) and
-    ends in its basis -- eta flushes, compact-column appends and deletes, ownership changes of
-    the pivot position and all."""
+@pytest.mark.parametrize("world,replicate", [(4, False), (8, False), (8, True), (3, True)])
+def test_sharded_whole_solve_follows_the_oracle_pivot_log(world, replicate):
+    """BASELINE config 2 (1024 x 2048) column-sharded over 3 / 4 / 8 ranks in lockstep on one GPU:
+    every rank takes the 21 642 pivots of the committed CPU-oracle log (tests/golden, 106 min of CPU)
+    and ends in its basis -- eta flushes, compact-column appends and deletes, ownership changes of
+    the pivot position and all.  Partitioned ranks run the separate phase kernels, ranks with a
+    replicated matrix the fused ones (k_chain_pre / k_chain_post between the exchanges)."""
     from dantzig_amd import core
     from dantzig_amd.sharded import make_lockstep, run_lockstep
 
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_pivots_1002_1024x2048.npz"))
     a, b, c = core.gen_dense_lp(seed=int(fx["seed"]), m=int(fx["m"]), n_struct=int(fx["n_struct"]))
     lp = core.CoreLP.from_inequality_form(a, b, c)
-    solvers = make_lockstep(lp, world, poll_interval=64)
+    solvers = make_lockstep(lp, world, replicate=replicate, poll_interval=64)
     try:
         status = run_lockstep(solvers)
         results = [s.result() for s in solvers]
