@@ -150,10 +150,12 @@ typedef struct {
                                  runner-up differ by less than max(tie_tol, 64 * max_pivot_error)
                                  relative, or rest on a denominator that is zero up to that
                                  tolerance.  Default 1e-11; < 0 switches the detector off       */
-    int32_t seven_launches;   /* FAST, dense matrix, one GPU: 0 (default) = an iteration is three
+    int32_t seven_launches;   /* FAST, dense matrix resident on the device (one GPU, or a column-sharded
+                                 rank with replicate_matrix): 0 (default) = an iteration is three
                                  launches (k_chain_pre, pricing, k_chain_post: device-wide barriers
-                                 inside, csrc/k_chain.hip); 1 = the seven launches a column-sharded
-                                 solver runs between its exchanges.  Same arithmetic, same pivots. */
+                                 inside, csrc/k_chain.hip; sharded: the same two kernels between the
+                                 exchanges); 1 = the seven launches a partitioned rank runs.  Same
+                                 arithmetic, same pivots. */
     int32_t reserved0;
 } dzg_opts;
 
