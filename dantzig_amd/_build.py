@@ -36,6 +36,7 @@ def _newest(paths) -> float:
 def _deps():
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "k_price_kernels.h"),
             os.path.join(CSRC, "fast_decide.h"), os.path.join(CSRC, "fast_rows.h"),
+            os.path.join(CSRC, "chain_barrier.h"),
             os.path.join(os.path.dirname(HERE), "include", "dantzig_amd.h")]
     return hdrs
 
