@@ -84,6 +84,9 @@ __device__ __forceinline__ double fast_gemv_row_head(int i, int m, int k2,
     const double *row = binv + (long long)i * ldb;
     double a0 = 0.0, a1 = 0.0;
     int c = 2 * sub;
+    // (unrolled: the loads of four steps leave together -- a wide inverse streams from HBM and one
+    // wave per row keeps too few bytes in flight otherwise -- the sums are taken in the same order)
+#pragma unroll 4
     for (; c + 2 * LPR < k2; c += 4 * LPR) {
         const double2_t r0 = *reinterpret_cast<const double2_t *>(row + c);
         const double2_t r1 = *reinterpret_cast<const double2_t *>(row + c + 2 * LPR);
