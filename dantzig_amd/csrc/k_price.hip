@@ -18,7 +18,7 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
     const dim3 grid(DZG_PRICE_TREE_BLOCKS), block(256);
     const int per_wave = (ncols + 4 * DZG_PRICE_TREE_BLOCKS - 1) / (4 * DZG_PRICE_TREE_BLOCKS);
     if (per_wave > 8)
-        hipLaunchKernelGGL((k_price_tree<16, 2>), grid, block, 0, st, PRICE_ARGS, pcode);
+        hipLaunchKernelGGL((k_price_tree<8, 2, 2>), grid, block, 0, st, PRICE_ARGS, pcode); // (2 passes of 8)
     else if (per_wave > 4)
         hipLaunchKernelGGL((k_price_tree<8, 4>), grid, block, 0, st, PRICE_ARGS, pcode);
     else if (per_wave > 2)

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_price_wave2(
 // inverse and is not bit-identical to the reference's anyway; the reference-order sums of
 // k_price_seq2 matter for STRICT numerics only.)
 // ---------------------------------------------------------------------------------
-template <int CW, int DEPTH>
+template <int CW, int DEPTH, int TP = 1>
 __global__ __launch_bounds__(256) void k_price_tree(
     const DzgCtl *ctl, const double *__restrict__ A, long long lda, int m, int q,
     const int *__restrict__ plist, const int *__restrict__ nonbasis,
@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256) void k_price_tree(
     const int start = wg * base + (wg < rem ? wg : rem);
     const int cnt = base + (wg < rem ? 1 : 0);
     const int ntiles = (m + TR - 1) / TR;
+    const int ngroups = (ntiles + TP - 1) / TP; // TP adjacent tiles of a column are fetched back to back
     const int lastpair = (int)lda - 2;
     const int lastv = ((m + 1) & ~1) - 2 >= 0 ? ((m + 1) & ~1) - 2 : 0;
 
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void k_price_tree(
             const int code_l = __builtin_amdgcn_readlane(mycode, l);
             off[l] = (long long)((code_l >= 0 ? code_l : lastcode) - col0) * lda;
         }
-        double2_t rg[DEPTH][CW], vg[DEPTH];
+        double2_t rg[DEPTH][TP][CW], vg[DEPTH][TP];
         double acc[CW];
 #pragma unroll
         for (int l = 0; l < CW; ++l) acc[l] = 0.0;
@@ -446,29 +447,43 @@ __global__ __launch_bounds__(256) void k_price_tree(
             }
         }
 
-        auto fetch = [&](int t, double2_t(&reg)[CW], double2_t &vreg) {
-            const int row = t * TR + 2 * lane;
-            const int rowc = row < lda ? row : lastpair;
+        // column-major: the TP tiles of a column leave back to back (TP KB contiguous per visit of
+        // a column: fewer DRAM row activations than 1 KB visits; 1-1.5 % at 8192 rows,
+        // profiles/r02_price_microbench_adjacent_tiles.txt); the sums keep their order (tiles
+        // ascending per column)
+        auto fetch = [&](int g, double2_t(&reg)[TP][CW], double2_t(&vreg)[TP]) {
 #pragma unroll
             for (int l = 0; l < CW; ++l)
-                reg[l] = __builtin_nontemporal_load(
-                    reinterpret_cast<const double2_t *>(A + off[l] + rowc));
-            vreg = *reinterpret_cast<const double2_t *>(v + (row < m ? row : lastv));
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    const int row = (g * TP + u) * TR + 2 * lane;
+                    const int rowc = row < lda ? row : lastpair;
+                    reg[u][l] = __builtin_nontemporal_load(
+                        reinterpret_cast<const double2_t *>(A + off[l] + rowc));
+                }
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                const int row = (g * TP + u) * TR + 2 * lane;
+                vreg[u] = *reinterpret_cast<const double2_t *>(v + (row < m ? row : lastv));
+            }
         };
         // rows >= m: the matrix holds zeros (padding) or, clamped, a repeated pair -- masked
-        auto consume = [&](int t, const double2_t(&reg)[CW], const double2_t &vreg) {
-            const bool inside = t * TR + 2 * lane < m; // v carries zero pads past m
+        auto consume = [&](int g, const double2_t(&reg)[TP][CW], const double2_t(&vreg)[TP]) {
 #pragma unroll
-            for (int l = 0; l < CW; ++l) {
-                const double ax = inside ? reg[l].x : 0.0, ay = inside ? reg[l].y : 0.0;
-                acc[l] = fma(ax, vreg.x, acc[l]);
-                acc[l] = fma(ay, vreg.y, acc[l]);
+            for (int u = 0; u < TP; ++u) {
+                const bool inside = (g * TP + u) * TR + 2 * lane < m; // v carries zero pads past m
+#pragma unroll
+                for (int l = 0; l < CW; ++l) {
+                    const double ax = inside ? reg[u][l].x : 0.0, ay = inside ? reg[u][l].y : 0.0;
+                    acc[l] = fma(ax, vreg[u].x, acc[l]);
+                    acc[l] = fma(ay, vreg[u].y, acc[l]);
+                }
             }
         };
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) fetch(d < ntiles ? d : ntiles - 1, rg[d], vg[d]);
+        for (int d = 0; d < DEPTH; ++d) fetch(d < ngroups ? d : ngroups - 1, rg[d], vg[d]);
         int t = 0;
-        for (; t + 2 * DEPTH - 1 < ntiles; t += DEPTH) {
+        for (; t + 2 * DEPTH - 1 < ngroups; t += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 consume(t + d, rg[d], vg[d]);
@@ -477,14 +492,14 @@ __global__ __launch_bounds__(256) void k_price_tree(
         }
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            if (t + d < ntiles) {
+            if (t + d < ngroups) {
                 consume(t + d, rg[d], vg[d]);
-                if (t + DEPTH + d < ntiles) fetch(t + DEPTH + d, rg[d], vg[d]);
+                if (t + DEPTH + d < ngroups) fetch(t + DEPTH + d, rg[d], vg[d]);
             }
         }
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
-            if (t + DEPTH + d < ntiles) consume(t + DEPTH + d, rg[d], vg[d]);
+            if (t + DEPTH + d < ngroups) consume(t + DEPTH + d, rg[d], vg[d]);
         // fold the 64 partial sums of every column; lane l keeps column l's total
         double mine = 0.0;
 #pragma unroll

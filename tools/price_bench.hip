@@ -36,6 +36,97 @@ __global__ __launch_bounds__(256) void k_stream(const double *__restrict__ a, si
     if (acc == 1.2345) out[0] = acc;
 }
 
+// Experiment (round 2): the tree kernel's stream with TP adjacent 128-row tiles of a column fetched
+// back to back (TP KB contiguous per column visit instead of 1 KB), same registers in flight as
+// <CW * TP, DEPTH, 1>.  Raw mode only (every position a column), sums in the same order.
+template <int CW, int DEPTH, int TP>
+__global__ __launch_bounds__(256) void k_tree_tp(const double *__restrict__ A, long long lda, int m, int q,
+                                                 const int *__restrict__ cols,
+                                                 const double *__restrict__ v, double *__restrict__ dz)
+{
+    constexpr int TR = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
+    const int base = q / nw, rem = q % nw;
+    const int start = wg * base + (wg < rem ? wg : rem), cnt = base + (wg < rem ? 1 : 0);
+    const int ntiles = (m + TR - 1) / TR, ngroups = (ntiles + TP - 1) / TP;
+    const int lastpair = (int)lda - 2;
+    const int lastv = ((m + 1) & ~1) - 2 >= 0 ? ((m + 1) & ~1) - 2 : 0;
+    for (int c0 = 0; c0 < cnt; c0 += CW) {
+        const int nc = (cnt - c0) < CW ? (cnt - c0) : CW;
+        int mycode = -1;
+        if (lane < nc) mycode = cols[start + c0 + lane];
+        long long off[CW];
+        int lastcode = 0;
+#pragma unroll
+        for (int l = 0; l < CW; ++l) {
+            const int code_l = __builtin_amdgcn_readlane(mycode, l);
+            if (code_l >= 0) lastcode = code_l;
+            off[l] = (long long)(code_l >= 0 ? code_l : lastcode) * lda;
+        }
+        double2_t rg[DEPTH][TP][CW], vg[DEPTH][TP];
+        double acc[CW];
+#pragma unroll
+        for (int l = 0; l < CW; ++l) acc[l] = 0.0;
+        auto fetch = [&](int g, double2_t(&reg)[TP][CW], double2_t(&vreg)[TP]) {
+#pragma unroll
+            for (int l = 0; l < CW; ++l) // column-major: the TP tiles of a column back to back
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    const int row = (g * TP + u) * TR + 2 * lane;
+                    const int rowc = row < lda ? row : lastpair;
+                    reg[u][l] = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(A + off[l] + rowc));
+                }
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                const int row = (g * TP + u) * TR + 2 * lane;
+                vreg[u] = *reinterpret_cast<const double2_t *>(v + (row < m ? row : lastv));
+            }
+        };
+        auto consume = [&](int g, const double2_t(&reg)[TP][CW], const double2_t(&vreg)[TP]) {
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                const bool inside = (g * TP + u) * TR + 2 * lane < m;
+#pragma unroll
+                for (int l = 0; l < CW; ++l) {
+                    const double ax = inside ? reg[u][l].x : 0.0, ay = inside ? reg[u][l].y : 0.0;
+                    acc[l] = fma(ax, vreg[u].x, acc[l]);
+                    acc[l] = fma(ay, vreg[u].y, acc[l]);
+                }
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d < ngroups ? d : ngroups - 1, rg[d], vg[d]);
+        int t = 0;
+        for (; t + 2 * DEPTH - 1 < ngroups; t += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                consume(t + d, rg[d], vg[d]);
+                fetch(t + DEPTH + d, rg[d], vg[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (t + d < ngroups) {
+                consume(t + d, rg[d], vg[d]);
+                if (t + DEPTH + d < ngroups) fetch(t + DEPTH + d, rg[d], vg[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (t + DEPTH + d < ngroups) consume(t + DEPTH + d, rg[d], vg[d]);
+        double mine = 0.0;
+#pragma unroll
+        for (int l = 0; l < CW; ++l) {
+            double s = acc[l];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == l) mine = s;
+        }
+        if (lane < nc && mycode >= 0) dz[start + c0 + lane] = -mine;
+    }
+}
+
 int main(int argc, char **argv)
 {
     int m = argc > 1 ? atoi(argv[1]) : 8192;
@@ -105,5 +196,9 @@ int main(int argc, char **argv)
     TREE(16, 2, 256); TREE(16, 3, 256); TREE(16, 4, 256); TREE(8, 4, 256); TREE(8, 4, 512); TREE(8, 6, 512);
     TREE(4, 8, 256); TREE(4, 8, 1024); TREE(4, 4, 1024); TREE(2, 16, 256); TREE(2, 8, 2048); TREE(1, 16, 2048);
     TREE(16, 2, 512); TREE(8, 8, 256);
+    // adjacent tiles of a column back to back (2 / 4 KB per column visit)
+#define TREETP(CW, DEP, TP, BLK) time_it("tree_tp<" #CW "," #DEP "," #TP "> x" #BLK, [&] { hipLaunchKernelGGL((k_tree_tp<CW, DEP, TP>), dim3(BLK), dim3(256), 0, 0, A, lda, m, ns, cols, v, dz); }, true)
+    TREETP(16, 2, 1, 256); TREETP(8, 2, 2, 256); TREETP(8, 2, 2, 512); TREETP(4, 2, 4, 256); TREETP(4, 2, 4, 512); TREETP(4, 2, 4, 1024);
+    TREETP(8, 3, 2, 256); TREETP(4, 4, 2, 512); TREETP(2, 2, 8, 1024); TREETP(16, 1, 2, 256);
     return 0;
 }
