@@ -357,6 +357,8 @@ struct DzgDev {
     int repl;            // 1: every structural column is resident (A points at column col0 of the
                          //    whole matrix, so `A + (code - col0) * lda` reaches any column)
     long long xstride;   // exchange record stride in doubles (8: header only, repl)
+    int price_cols_hint; // host's last reading of ctl->nb_struct (0: unknown): picks the pricing
+                         // kernel's pass shape; any shape is correct for any count
 };
 
 #ifdef __HIPCC__

@@ -912,6 +912,7 @@ static int run_fast(dzg_solver *s)
         const long long before = s->h_ctl->iter;
         const int batch = batch_size(s);
         s->since_flush = s->h_ctl->neta; // pending etas as the device counts them
+        s->d.price_cols_hint = (int)s->h_ctl->nb_struct + batch; // (at most one more per pivot)
         if (s->d.spb) {
             for (int b = 0; b < batch; ++b) enqueue_sparse_iteration(s, b);
         } else if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
@@ -1209,6 +1210,7 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         s->since_flush = s->h_ctl->neta;
         s->since_refactor += batch;
         s->batch_chain = s->chain_bar && (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
+        s->d.price_cols_hint = (int)s->h_ctl->nb_struct + batch;
         for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
@@ -1281,6 +1283,7 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
             sv[r]->since_refactor += batch;
             sv[r]->batch_chain =
                 sv[r]->chain_bar && (long long)sv[r]->h_ctl->ncompact + batch <= sv[r]->chain_kcap;
+            sv[r]->d.price_cols_hint = (int)sv[r]->h_ctl->nb_struct + batch;
         }
         for (int b = 0; b < batch; ++b) {
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));

@@ -17,8 +17,13 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
 {
     const dim3 grid(DZG_PRICE_TREE_BLOCKS), block(256);
     const int per_wave = (ncols + 4 * DZG_PRICE_TREE_BLOCKS - 1) / (4 * DZG_PRICE_TREE_BLOCKS);
-    if (per_wave > 8)
-        hipLaunchKernelGGL((k_price_tree<8, 2, 2>), grid, block, 0, st, PRICE_ARGS, pcode); // (2 passes of 8)
+    // 15-16 columns per wave: two full passes of 8 with 2-KiB visits (160.8 us against 162.7 at 8192
+    // rows); 9-14: the second pass would be half empty -- one pass of 16 (at 11 columns per wave,
+    // k = 4 920: 125.8 us against 133.2; profiles/r02_price_shape_deep_in_the_solve.txt)
+    if (per_wave > 14)
+        hipLaunchKernelGGL((k_price_tree<8, 2, 2>), grid, block, 0, st, PRICE_ARGS, pcode);
+    else if (per_wave > 8)
+        hipLaunchKernelGGL((k_price_tree<16, 2>), grid, block, 0, st, PRICE_ARGS, pcode);
     else if (per_wave > 4)
         hipLaunchKernelGGL((k_price_tree<8, 4>), grid, block, 0, st, PRICE_ARGS, pcode);
     else if (per_wave > 2)
@@ -98,7 +103,11 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
     // (column codes per nonbasic position, kept by the pivot's books: one load instead of
     // nonbasis[] -> var_col[] before a wave knows where its columns are)
     // pcode[i] = code of the column at plist[i]: a wave learns its columns in one trip
-    launch(kernel, d.col1 - d.col0, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nbcode, nullptr, d.v, d.dz, d.z,
+    // the pass shape follows the number of nonbasic structural columns as the host last read it
+    // (the kernel takes the exact count from the control block: a stale hint costs speed only)
+    int ncols = d.col1 - d.col0;
+    if (d.price_cols_hint > 0 && d.price_cols_hint < ncols) ncols = d.price_cols_hint;
+    launch(kernel, ncols, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nbcode, nullptr, d.v, d.dz, d.z,
            d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, d.pcode, st);
 }
 
