@@ -36,7 +36,7 @@ EXPORTS = [
     "dzg_solver_poll", "dzg_solver_set_budget", "dzg_comm_unique_id", "dzg_shard_comm_init",
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
     "dzg_gen_dense_lp_block", "dzg_solver_set_profile", "dzg_kernel_neg_t_dot_csc",
-    "dzg_shard_comm_size", "dzg_solver_upload_columns",
+    "dzg_shard_comm_size", "dzg_solver_upload_columns", "dzg_debug_hold_cus", "dzg_debug_hold_wait",
 ]
 
 
@@ -78,6 +78,7 @@ class Result(C.Structure):
         ("price_bytes", C.c_double), ("solve_ms", C.c_double), ("max_pivot_error", C.c_double),
         ("near_ties", C.c_int64), ("first_near_tie", C.c_int64), ("min_margin", C.c_double),
         ("margins", C.c_void_p), ("dense_columns", C.c_int64), ("refactors", C.c_int64),
+        ("chain_fallbacks", C.c_int64),
     ]
 
 
@@ -156,6 +157,7 @@ def lib() -> C.CDLL:
         _lib.dzg_solver_stream.argtypes = [C.c_void_p]
         _lib.dzg_solver_refactor.argtypes = [C.c_void_p]
         _lib.dzg_solver_set_profile.argtypes = [C.c_void_p, C.c_int32]
+        _lib.dzg_debug_hold_cus.argtypes = [C.c_int32, C.c_int32, C.c_double]
         _lib.dzg_solver_upload_columns.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                                    C.c_int64]
     return _lib

@@ -117,6 +117,7 @@ class CoreResult:
     margins: np.ndarray | None = None   # per-pivot smallest decision margin (log=True)
     dense_columns: int = 0              # k: structural basics = dense columns of the inverse
     refactors: int = 0
+    chain_fallbacks: int = 0            # failed device-wide barriers recovered from (k_chain.hip)
 
 
 class Solver:
@@ -196,7 +197,8 @@ class Solver:
             price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms),
             max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
             first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin), margins=margins,
-            dense_columns=int(r.dense_columns), refactors=int(r.refactors))
+            dense_columns=int(r.dense_columns), refactors=int(r.refactors),
+            chain_fallbacks=int(r.chain_fallbacks))
 
     def set_profile(self, mask: int) -> None:
         """Which kernel classes (bits 1 << _ffi.K_*) the following runs time with HIP events."""
@@ -260,7 +262,7 @@ def core_solve(lp: CoreLP, log_cap: int = 1 << 20, **opts) -> CoreResult:
             max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
             first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin),
             margins=margins[:cnt].copy(), dense_columns=int(r.dense_columns),
-            refactors=int(r.refactors))
+            refactors=int(r.refactors), chain_fallbacks=int(r.chain_fallbacks))
 
 
 # ------------------------------------------------------------------ synthetic LPs

@@ -424,6 +424,8 @@ void dzg_launch_lockstep_allgather(double *const *ptrs, int world, int which, lo
 
 // k_chain.hip: the FAST iteration of the dense inverse in three launches (one GPU)
 #define DZG_CHAIN_AGCAP 16384 // compact width up to which the chain runs (the gathered column in LDS)
+#define DZG_CHAIN_BAR_WORDS (16 * 10) // barrier counters (chain_barrier.h: CH_BAR_WORDS)
+int dzg_chain_resident_per_cu(void); // workgroups of the chain kernels the runtime places on one CU
 void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
                           unsigned long long *dbg, const double *xrecv, hipStream_t st);
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,

@@ -110,12 +110,14 @@ struct dzg_solver {
     double max_err_life = 0.0; // largest ctl->max_pivot_err ever read (the device value restarts
                                // at every refactorisation)
     // FAST, dense, one GPU: the three-launch chain (k_chain.hip)
-    unsigned long long *chain_bar = nullptr; // barrier counters (never reset)
+    unsigned long long *chain_bar = nullptr; // barrier counters (cleared only by chain_recover)
     unsigned long long *chain_dbg = nullptr; // DZG_CHAIN_DEBUG=1: phase clocks of workgroup 0
     int chain_grid = 0;                      // one workgroup per CU
     long long chain_kcap = DZG_CHAIN_AGCAP;  // compact width beyond which a batch runs as seven
                                              // launches (DZG_CHAIN_KCAP lowers it: tests)
     bool batch_chain = false;                // the batch in flight runs the chain
+    int64_t chain_fallbacks = 0;             // barrier failures recovered from (chain_recover)
+    long long chain_retry_iter = 0;          // the chain stays off until this pivot count
     // column sharding
     void *comm = nullptr;                  // ncclComm_t
     double *xsend = nullptr, *xrecv1 = nullptr, *xrecv2 = nullptr;
@@ -572,15 +574,24 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         }
         // one GPU, or a column-sharded rank that keeps the whole matrix (the entering column is local)
         if ((d.world == 1 || d.repl) && !d.csc && !o.seven_launches) {
-            // the chain's barriers need every workgroup resident at once: one per CU
+            // the chain's barriers need every workgroup resident at once: one per CU, and the
+            // runtime must agree that a workgroup of either kernel fits a CU at all (registers,
+            // 136 KB of LDS); otherwise the barrier-free seven launches run
             hipDeviceProp_t prop;
             HIP_OK(hipGetDeviceProperties(&prop, o.device));
             int grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
             if (grid > 256) grid = 256; // (k_chain_pre reads <= 256 candidates)
+            const int per_cu = dzg_chain_resident_per_cu();
+            if (per_cu < 1) grid = 0;
+            if (const char *g = std::getenv("DZG_CHAIN_GRID")) { // tests: a device with few CUs
+                const int v = std::atoi(g);
+                if (v >= 1 && v < grid) grid = v;
+            }
             // a thread takes one row and one column of its workgroup's share (512 threads)
-            const long long rows_per = (((long long)m + grid - 1) / grid + 3) & ~3ll;
-            const long long cols_per = ((long long)q + grid - 1) / grid;
-            if (rows_per <= 512 && cols_per <= 512) {
+            const int gdiv = grid > 0 ? grid : 1;
+            const long long rows_per = (((long long)m + gdiv - 1) / gdiv + 3) & ~3ll;
+            const long long cols_per = ((long long)q + gdiv - 1) / gdiv;
+            if (grid >= 1 && rows_per <= 512 && cols_per <= 512) {
                 s->chain_grid = grid;
                 if (const char *cap = std::getenv("DZG_CHAIN_KCAP")) {
                     const long long v = std::atoll(cap);
@@ -592,8 +603,8 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                         HIP_OK(hipMemsetAsync(s->chain_dbg, 0, sizeof(unsigned long long) * 64, s->st));
                     }
                 }
-                TRY(dev_alloc(s, &s->chain_bar, (size_t)16 * 9));
-                HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * 16 * 9, s->st));
+                TRY(dev_alloc(s, &s->chain_bar, (size_t)DZG_CHAIN_BAR_WORDS));
+                HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * DZG_CHAIN_BAR_WORDS, s->st));
             }
         }
         dzg_launch_fast_init(d, s->st);
@@ -901,6 +912,30 @@ static int budget_spent(dzg_solver *s, bool *spent)
     return 0;
 }
 
+// A device-wide barrier of the three-launch iteration failed (its workgroups were not all resident:
+// another kernel holds CUs or LDS of this device).  chain_barrier fails CONSISTENTLY -- every
+// workgroup of the launch alike -- and both chain kernels write nothing but scratch (dx, v, beta,
+// candidates, the decision fields of the control block) before their last barrier, and every
+// later launch of the batch saw status != RUNNING: the solver state is that of the last completed
+// pivot.  Clear the counters, carry on with the barrier-free seven launches (same arithmetic, same
+// pivots) and give the chain another chance later; after three failures it stays off.
+static int chain_recover(dzg_solver *s)
+{
+    DzgCtl *h = s->h_ctl;
+    s->chain_fallbacks += 1;
+    s->chain_retry_iter = s->chain_fallbacks >= 3 ? std::numeric_limits<long long>::max()
+                                                  : h->iter + 64ll * s->opts.poll_interval;
+    HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * DZG_CHAIN_BAR_WORDS, s->st));
+    h->status = DZG_RUNNING;
+    h->bar_timeout = 0;
+    h->bar_gen = 0;
+    HIP_OK(hipMemcpyAsync(&s->d.ctl->status, &h->status, sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIP_OK(hipMemcpyAsync(&s->d.ctl->bar_timeout, &h->bar_timeout, sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIP_OK(hipMemcpyAsync(&s->d.ctl->bar_gen, &h->bar_gen, sizeof(unsigned long long), hipMemcpyHostToDevice, s->st));
+    HIP_OK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
 static int run_fast(dzg_solver *s)
 {
     for (;;) {
@@ -930,7 +965,8 @@ static int run_fast(dzg_solver *s)
         } else {
             // the chain keeps the gathered entering column in LDS: beyond that compact width
             // (k grows by at most one per pivot) the batch runs as seven launches
-            s->batch_chain = s->chain_bar && (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
+            s->batch_chain = s->chain_bar && s->h_ctl->iter >= s->chain_retry_iter &&
+                             (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
             if (s->batch_chain)
                 for (int b = 0; b < batch; ++b) enqueue_chain_iteration(s, b);
             else
@@ -939,10 +975,10 @@ static int run_fast(dzg_solver *s)
         s->since_refactor += batch;
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
-        if (s->h_ctl->bar_timeout)
-            return fail(DZG_E_DEVICE, "a device-wide barrier of the three-launch iteration timed out: its "
-                                      "workgroups were not all resident (is another kernel holding CUs or "
-                                      "LDS on this device?); opts.seven_launches = 1 runs without barriers");
+        if (s->h_ctl->bar_timeout) { // the batch ended at a failed barrier: carry on without barriers
+            TRY(chain_recover(s));
+            continue;
+        }
         collect_profile(s, (int)(s->h_ctl->iter - before));
         if (s->h_ctl->status != DZG_RUNNING) break;
         bool stop = false;
@@ -1390,6 +1426,7 @@ extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
     res->min_margin = s->h_ctl->min_margin;
     res->dense_columns = s->numerics == DZG_NUMERICS_FAST ? s->h_ctl->ncompact : 0;
     res->refactors = s->refactors;
+    res->chain_fallbacks = s->chain_fallbacks;
     if (res->margins && res->log_cap > 0 && s->numerics == DZG_NUMERICS_FAST) {
         long long cnt = res->iterations < d.log_cap ? res->iterations : d.log_cap;
         if (cnt > res->log_cap) cnt = res->log_cap;

@@ -176,15 +176,17 @@ __device__ __forceinline__ void chain_stage_ag(double *s_ag, int k, int code,
 __device__ __forceinline__ void chain_beta(const DzgDev &d, int neta, int code,
                                            const double *__restrict__ a)
 {
-    const int b = blockIdx.x;
-    if (b >= neta) return; // (block-uniform)
-    const double *wt = d.W + (long long)b * d.ldw;
-    double acc;
-    if (code < 0)
-        acc = wt[-1 - code];
-    else
-        acc = fast_beta_dot(wt, a, d.m);
-    if (threadIdx.x == 0) st_sc1(d.beta + b, acc);
+    // (block-uniform loop: a grid of fewer workgroups than pending etas -- a CU-masked or
+    // partitioned device -- takes several rows per workgroup; same bits, beta_t depends on t only)
+    for (int b = blockIdx.x; b < neta; b += gridDim.x) {
+        const double *wt = d.W + (long long)b * d.ldw;
+        double acc;
+        if (code < 0)
+            acc = wt[-1 - code];
+        else
+            acc = fast_beta_dot(wt, a, d.m);
+        if (threadIdx.x == 0) st_sc1(d.beta + b, acc);
+    }
 }
 
 // FTRAN on this workgroup's rows, first half (needs the gathered column only): lane group `grp` of
@@ -718,6 +720,24 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
     ts.done(slot);
 }
 
+static_assert(CH_BAR_WORDS == DZG_CHAIN_BAR_WORDS, "barrier counter block");
+
+// Residency of the chain kernels as the runtime computes it (registers, LDS, 512 threads): the
+// smallest count over the four instantiations; 0 = some kernel does not fit a CU at all.
+int dzg_chain_resident_per_cu(void)
+{
+    int least = 1 << 20, n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_chain_pre<false>, CH_THREADS, 0) != hipSuccess) return 0;
+    least = n < least ? n : least;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_chain_pre<true>, CH_THREADS, 0) != hipSuccess) return 0;
+    least = n < least ? n : least;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_chain_post<false>, CH_THREADS, 0) != hipSuccess) return 0;
+    least = n < least ? n : least;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_chain_post<true>, CH_THREADS, 0) != hipSuccess) return 0;
+    least = n < least ? n : least;
+    return least;
+}
+
 // xrecv != nullptr: a column-sharded rank (replicated matrix), records of the exchange just done
 void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
                           unsigned long long *dbg, const double *xrecv, hipStream_t st)
@@ -738,4 +758,47 @@ void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
     else
         hipLaunchKernelGGL(k_chain_post<false>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar,
                            dzg_pivot_args(d), only_partials, nrz, dbg, xrecv);
+}
+
+// ---------------------------------------------------------------------------------
+// Test hook: a co-tenant on the device.  Each workgroup keeps 128 KB of LDS (so that no chain
+// workgroup -- 136 KB -- fits beside it on the CU) and watches the 100 MHz clock until the time is
+// up: an exit every wave reaches.  Launched on a stream of its own.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_debug_hold(unsigned long long ticks, int *sink)
+{
+    extern __shared__ double s_hold[];
+    s_hold[threadIdx.x] = 1.0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long spins = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && spins < (1ull << 34)) {
+        __builtin_amdgcn_s_sleep(64);
+        ++spins;
+    }
+    if (s_hold[threadIdx.x] == 2.0) *sink = 1; // (keeps the allocation alive)
+}
+
+static hipStream_t g_hold_stream = nullptr;
+static int *g_hold_sink = nullptr;
+
+extern "C" int dzg_debug_hold_cus(int32_t device, int32_t workgroups, double seconds)
+{
+    if (workgroups < 1 || workgroups > 256 || !(seconds > 0.0) || seconds > 30.0) return DZG_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return DZG_E_DEVICE;
+    const int lds = 128 * 1024;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_debug_hold),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return DZG_E_DEVICE;
+    if (!g_hold_stream && hipStreamCreateWithFlags(&g_hold_stream, hipStreamNonBlocking) != hipSuccess)
+        return DZG_E_DEVICE;
+    if (!g_hold_sink && hipMalloc(&g_hold_sink, sizeof(int)) != hipSuccess) return DZG_E_NOMEM;
+    hipLaunchKernelGGL(k_debug_hold, dim3(workgroups), dim3(64), lds, g_hold_stream,
+                       (unsigned long long)(seconds * 1e8), g_hold_sink);
+    return hipGetLastError() == hipSuccess ? 0 : DZG_E_DEVICE;
+}
+
+extern "C" int dzg_debug_hold_wait(void)
+{
+    if (!g_hold_stream) return 0;
+    return hipStreamSynchronize(g_hold_stream) == hipSuccess ? 0 : DZG_E_DEVICE;
 }

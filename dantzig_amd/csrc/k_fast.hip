@@ -413,7 +413,10 @@ __global__ __launch_bounds__(256) void k_fast_gather_w(const DzgCtl *ctl, const 
                                                        long long ldw, const int *__restrict__ drow,
                                                        double *__restrict__ Wc)
 {
-    if (ctl->neta <= 0) return;
+    // a flush folds a FULL eta file: one enqueued behind an iteration that did not pivot (the run
+    // stopped, a barrier failed) is a no-op, so the flush falls after the same pivots whatever
+    // happens in between -- results stay reproducible bit for bit
+    if (ctl->neta < R_) return;
     const int k = ctl->ncompact, neta = ctl->neta;
     const int t = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int 
                                                          long long ldw)
 {
     const int neta = ctl->neta, k = ctl->ncompact;
-    if (neta <= 0 || k <= 0) return;
+    if (neta < R_ || k <= 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64;
     const int i0 = (blockIdx.y * 4 + wave) * 16;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int 
 
 __global__ void k_fast_flush_done(DzgCtl *ctl)
 {
-    ctl->neta = 0;
+    if (ctl->neta >= R_) ctl->neta = 0;
 }
 
 __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, int *dslot,

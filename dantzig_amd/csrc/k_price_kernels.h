@@ -192,9 +192,14 @@ __global__ __launch_bounds__(256) void k_price_seq2(
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int l = 0; l < CW; ++l) {
+                // The reference's CSC drops exact zeros (src/linalg.rs:254-270), so neg_t_dot never
+                // forms 0 * -v[i]; the dense layout keeps them, and 0 * (-/+inf) or 0 * NaN would
+                // put a NaN where the reference skips the entry.  A skipped entry is the
+                // addition of +0.0 here: the running sum starts at +0.0 and can never be -0.0
+                // (x + -x = +0.0), so adding +0.0 leaves every bit of it.
                 double2_t pr;
-                pr.x = reg[l].x * nv0;
-                pr.y = reg[l].y * nv1;
+                pr.x = reg[l].x != 0.0 ? reg[l].x * nv0 : 0.0;
+                pr.y = reg[l].y != 0.0 ? reg[l].y * nv1 : 0.0;
                 *reinterpret_cast<double2_t *>(&mytile[l][2 * lane]) = inside ? pr : zero;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

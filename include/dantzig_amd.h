@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DZG_ABI_VERSION 2
+#define DZG_ABI_VERSION 3
 
 /* Outcome codes.  0..2 mirror the reference: Ok / Error::Unbounded / Error::Infeasible
  * (src/error.rs:3-7, src/simplex.rs:313,325).  The rest do not exist in the
@@ -216,6 +216,9 @@ typedef struct {
     /* FAST basis representation */
     int64_t dense_columns;   /* k: structural variables in the basis = dense columns of the inverse */
     int64_t refactors;       /* refactorisations performed so far                               */
+    int64_t chain_fallbacks; /* three-launch iteration: device-wide barriers that failed (another
+                                kernel held CUs or LDS of the device) and were recovered from by
+                                running on without barriers; 0 on an undisturbed device            */
 } dzg_result;
 
 typedef struct dzg_solver dzg_solver;
@@ -407,6 +410,13 @@ int dzg_solver_set_profile(dzg_solver *s, int32_t mask);
 int dzg_solver_poll(dzg_solver *s, int32_t *status, int64_t *iterations);
 /* Sets the run budget like dzg_solver_run does, without running (sharded hosts drive the loop). */
 int dzg_solver_set_budget(dzg_solver *s, int64_t max_new_iters);
+
+/* Test hook (tests/test_gpu_parity.py, tools/): occupies `workgroups` CUs of `device` for about
+ * `seconds` with a kernel that holds 128 KB of LDS per workgroup and watches the clock, on a
+ * stream of its own; returns at once.  dzg_debug_hold_wait waits for it.  This is how the
+ * three-launch iteration's recovery from a co-tenant on the device is exercised. */
+int dzg_debug_hold_cus(int32_t device, int32_t workgroups, double seconds);
+int dzg_debug_hold_wait(void);
 
 /* Deterministic max-loc merge: largest ratio wins, lowest global position on ties --
  * the sequential first-wins rule of src/simplex.rs:432-435,456-459.  Returns the index

@@ -1,0 +1,62 @@
+"""First pivots of a seeded G1 LP under the CPU oracle (the C restatement of the reference's
+arithmetic, oracle/) at sizes where one pivot costs the oracle half a minute to several minutes
+(two dense LUs of B and of B^T from scratch per iteration, as src/simplex.rs:226-236 does):
+tests/golden/oracle_first_pivots_<seed>_<m>x<ns>.json.
+
+The oracle's state (basis, nonbasis, x, xbar, z, zbar) lives in the arrays handed to
+ora_simplex_solve, so the solve is advanced ONE pivot per call and the fixture is rewritten after
+every pivot: an interrupted run keeps what it has.  Each record is what
+src/simplex.rs:274-306,308-330 decides -- (kind, entering, leaving) -- with mu* of that
+iteration and the seconds of CPU the pivot took on one core of the machine that ran this.
+
+  python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots
+  (BASELINE config 3: 1003 8192 16384 8  -- about 6.5 minutes per pivot)
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from dantzig_amd import core  # noqa: E402  (host-side generator only, no GPU needed)
+from oracle import oracle as ora  # noqa: E402
+
+if __name__ == "__main__":
+    seed, m, ns, pivots = (int(v) for v in sys.argv[1:5])
+    path = os.path.join(ROOT, "tests", "golden", f"oracle_first_pivots_{seed}_{m}x{ns}.json")
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    sf = ora.stdform_from_dense(a, b, c)
+    del a
+    n, q = sf.n, sf.n - sf.m
+    basis, nonbasis = ora._i64(sf.basis).copy(), ora._i64(sf.nonbasis).copy()
+    x, z = ora._f64(sf.x).copy(), ora._f64(sf.z).copy()
+    xbar, zbar = np.ones(m), np.ones(q)
+    col_ptr, row_idx, val, cc = ora._i64(sf.col_ptr), ora._i64(sf.row_idx), ora._f64(sf.val), ora._f64(sf.c)
+    st = ora._Simplex(m, n, ora._p(col_ptr), ora._p(row_idx), ora._p(val), ora._p(cc), float(sf.constant),
+                      ora._p(basis), ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
+    out = {"seed": seed, "m": m, "n_struct": ns, "generator": "G1 (dantzig_amd.core.gen_dense_lp)",
+           "source": "oracle/dzg_oracle.c, one ora_simplex_solve(max_iter=1) call per pivot",
+           "kind": [], "entering": [], "leaving": [], "mu": [], "seconds_per_pivot": []}
+    log = (ora._Pivot * 1)()
+    for k in range(pivots):
+        iters = C.c_int64(0)
+        t0 = time.perf_counter()
+        status = ora.lib().ora_simplex_solve(C.byref(st), C.c_int64(1), C.byref(iters), log, C.c_int64(1))
+        dt = time.perf_counter() - t0
+        if iters.value != 1:
+            out["status_after"] = ora.STATUS[status]
+            break
+        out["kind"].append(int(log[0].kind))
+        out["entering"].append(int(log[0].entering))
+        out["leaving"].append(int(log[0].leaving))
+        out["mu"].append(float(log[0].mu))
+        out["seconds_per_pivot"].append(round(dt, 1))
+        with open(path + ".tmp", "w") as f:
+            json.dump(out, f)
+        os.replace(path + ".tmp", path)
+        print(f"pivot {k + 1}: {(log[0].kind, log[0].entering, log[0].leaving)} mu {log[0].mu!r} "
+              f"in {dt:.1f} s", flush=True)

@@ -591,6 +591,63 @@ def test_strict_follows_the_oracle_through_degenerate_lps(core):
     assert {"optimal", "unbounded", "panic", "infeasible"} <= outcomes
 
 
+def _csc_lp(core, a, b, c):
+    """The same LP with its structural block in CSC (zeros dropped, src/linalg.rs:254-270)."""
+    cp, ri, val = ora.csc_from_dense(np.asarray(a, dtype=np.float64))
+    return core.CoreLP.from_csc(a.shape[0], cp, ri, val, b, c)
+
+
+def test_neg_t_dot_skips_stored_zeros_as_the_reference_csc_does(core):
+    """The reference's CSC holds no exact zeros (src/linalg.rs:254-270), so neg_t_dot
+    (src/linalg.rs:199-207) never forms 0 * -v[i]; the device keeps dense columns, zeros included.
+    With v = +/-inf or NaN in a row where a column holds a zero the reference SKIPS the entry and a
+    plain product would give NaN: the sequential-order kernel must skip it too."""
+    rng = np.random.default_rng(99)
+    for m, ns in [(5, 7), (130, 40), (300, 33)]:
+        a = rng.integers(-3, 4, (m, ns)).astype(np.float64)
+        a[rng.uniform(size=a.shape) < 0.4] = 0.0
+        a[0, 0] = -0.0  # a negative zero is dropped as well (`!= 0.0` is false for it)
+        v = rng.integers(-4, 5, m).astype(np.float64)
+        bad = rng.permutation(m)[:3]
+        v[bad] = [np.inf, -np.inf, np.nan]
+        a[np.ix_(bad, np.arange(ns))] *= rng.uniform(size=(3, ns)) < 0.3  # mostly zeros in those rows
+        cols = np.concatenate([np.arange(ns), -1 - bad[:3]])
+        full = np.concatenate([a, np.eye(m)], axis=1)
+        cp, ri, val = ora.csc_from_dense(full)
+        ocols = np.where(cols >= 0, cols, ns + (-1 - cols))
+        want = ora.neg_t_dot(cp, ri, val, ocols, v)
+        got = core.neg_t_dot(a, cols, v, kernel=core.PRICE_SEQ)
+        assert _same_bits(got, want), (m, ns, np.flatnonzero(~((got == want) | (np.isnan(got) & np.isnan(want)))))
+        # the case is not vacuous: columns that are finite although v is not (a plain product over
+        # the dense column would make every one of them NaN), and columns that are not finite
+        assert np.isfinite(want[:ns]).any() and (~np.isfinite(want[:ns])).any()
+        with np.errstate(invalid="ignore"):
+            assert not np.isfinite(a.T @ v).any()
+        # the CSC kernel (stored entries only) is the same function
+        gcsc = core.neg_t_dot_csc(m, cp[:ns + 1], ri[:cp[ns]], val[:cp[ns]], cols, v)
+        assert _same_bits(gcsc, want), (m, ns)
+
+
+@pytest.mark.parametrize("seed", [1932, 2656, 4366, 4538])
+def test_strict_follows_the_oracle_where_zero_meets_a_non_finite_v(core, seed):
+    """Small-integer LPs on which the reference reaches a non-finite v (BTRAN through a singular
+    basis) while nonbasic columns hold zeros in those rows: the reference panics after 6 / 4 / 9 / 8
+    pivots (`safe_divide`'s assert); with 0 * inf = NaN in the pricing pass the outcome would be
+    `infeasible` instead (`make_lp(seed, 1, 1, 25)`)."""
+    from tests.lp_families import make_lp
+
+    a, b, c = make_lp(seed, 1, 1, 25)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=5000)
+    assert want.status == "panic"
+    for lp in (core.CoreLP.from_inequality_form(a, b, c), _csc_lp(core, a, b, c)):
+        got = core.solve(lp, numerics=core.STRICT, max_iter=5000)
+        assert got.status == want.status, seed
+        assert _log(got) == _log(want), seed
+        assert _same_bits([p[3] for p in got.pivots], [p[3] for p in want.pivots]), seed
+        for name in ("x", "xbar", "z", "zbar"):
+            assert _same_bits(getattr(got, name), getattr(want, name)), (seed, name)
+
+
 def test_whole_solve_from_csc_follows_the_oracle_pivot_log(core):
     """The 512 x 1024 LP of the committed oracle log handed over as CSC (every entry stored): the
     sparse device path -- CSC pricing in the reference's order, entering columns densified into
@@ -893,6 +950,56 @@ def test_chain_hands_over_to_seven_launches_when_the_inverse_outgrows_lds(core, 
     assert r7.dense_columns > 24  # the cap was crossed
     want = ora.simplex_solve(ora.stdform_from_dense(np.array(a), b, c), max_iter=100000)
     assert log3(r3.pivots) == log3(want.pivots) and r3.status == want.status
+
+
+def test_chain_on_a_grid_smaller_than_the_eta_file(core, monkeypatch):
+    """A device (or partition) with fewer CUs than the eta file has rows -- 64: beta_t = W_t . a_j is
+    computed by workgroup t, so a grid of 8 or 24 workgroups must take several rows each (ADVICE r2:
+    a grid below 64 left beta[grid..neta) stale).  DZG_CHAIN_GRID forces the grid; the solve must
+    stay the seven-launch solve bit for bit, and the oracle's pivot log."""
+    from tests.lp_families import log3
+
+    a, b, c = core.gen_dense_lp(seed=9401, m=200, n_struct=420)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    r7 = core.solve(lp, numerics=core.FAST, poll_interval=16, seven_launches=1)
+    assert r7.iterations > 500  # the eta file fills (64 rows) and is flushed many times
+    for grid in ("8", "24", "100"):
+        monkeypatch.setenv("DZG_CHAIN_GRID", grid)
+        r3 = core.solve(lp, numerics=core.FAST, poll_interval=16)
+        assert _same_solution(r3, r7), grid
+    monkeypatch.delenv("DZG_CHAIN_GRID")
+    want = ora.simplex_solve(ora.stdform_from_dense(np.array(a), b, c), max_iter=100000)
+    assert log3(r7.pivots) == log3(want.pivots) and r7.status == want.status == "optimal"
+
+
+def test_chain_recovers_when_another_kernel_holds_compute_units(core):
+    """The three-launch iteration needs all of its workgroups resident at once (device-wide barriers,
+    csrc/chain_barrier.h).  With a co-tenant on the device -- here a kernel that keeps 8 CUs busy for
+    3 s with 128 KB of LDS each, so no chain workgroup fits beside it -- a barrier gives up after
+    2.4 s; it fails for EVERY workgroup alike, nothing of the iteration has been written yet, and the
+    host carries on with the barrier-free seven launches (engine.hip, chain_recover) instead of
+    returning DZG_E_DEVICE.  The solve must end optimal with the oracle's pivot log
+    and, bit for bit, the undisturbed solve's numbers."""
+    import ctypes as C
+
+    from dantzig_amd import _ffi
+    from tests.lp_families import log3
+
+    a, b, c = core.gen_dense_lp(seed=9501, m=256, n_struct=512)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    calm = core.solve(lp, numerics=core.FAST, poll_interval=16)
+    assert calm.status == "optimal" and calm.chain_fallbacks == 0
+    with core.Solver(lp, numerics=core.FAST, poll_interval=16) as s:
+        assert s.run(100) == "iter_limit"  # the chain is up and running
+        _ffi.check(_ffi.lib().dzg_debug_hold_cus(C.c_int32(0), C.c_int32(8), C.c_double(3.0)), "hold")
+        status = s.run(0)
+        got = s.result()
+    _ffi.check(_ffi.lib().dzg_debug_hold_wait(), "hold_wait")
+    assert status == "optimal"
+    assert got.chain_fallbacks >= 1, "the co-tenant did not get in the chain's way: the test tested nothing"
+    assert _same_solution(got, calm)
+    want = ora.simplex_solve(ora.stdform_from_dense(np.array(a), b, c), max_iter=100000)
+    assert log3(got.pivots) == log3(want.pivots) and want.status == "optimal"
 
 
 def test_chain_and_seven_launches_agree_over_a_whole_solve_of_config_2(core):

@@ -38,7 +38,7 @@ int main()
     double *buf;
     int *errors;
     CK(hipMalloc(&ctl, sizeof(DzgCtl)));
-    CK(hipMalloc(&bar, sizeof(unsigned long long) * 16 * 9));
+    CK(hipMalloc(&bar, sizeof(unsigned long long) * CH_BAR_WORDS));
     CK(hipMalloc(&buf, sizeof(double) * 1024));
     CK(hipMalloc(&errors, sizeof(int)));
     DzgCtl h;
@@ -47,7 +47,7 @@ int main()
         std::memset(&h, 0, sizeof(h));
         h.status = DZG_RUNNING;
         CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
-        CK(hipMemset(bar, 0, sizeof(unsigned long long) * 16 * 9));
+        CK(hipMemset(bar, 0, sizeof(unsigned long long) * CH_BAR_WORDS));
         CK(hipMemset(errors, 0, sizeof(int)));
         const int rounds = absent < 0 ? 1000 : 1;
         auto t0 = std::chrono::steady_clock::now();
