@@ -105,10 +105,16 @@ def run_lockstep(solvers: list, max_new_iters: int = 0) -> str:
 
 # ------------------------------------------------------------------ bench.py, N > 1
 def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, rank, world,
-                     local_rank) -> dict:
+                     local_rank, replicate: bool) -> dict:
     """One dense G1 workload, column-sharded over `world` ranks.  Every rank generates only its own
     column block (dzg_gen_dense_lp_block: bit-identical to that slice of the whole LP, b and c
-    complete), so no process ever holds the whole matrix.  Collective: every rank returns."""
+    complete), so no process ever holds the whole matrix on the host.  Collective: every rank
+    returns.
+
+    replicate=False -- the PARTITIONED storage BASELINE.json's north star names: a rank's HBM holds
+    its column block only, the entering column travels in the exchange records (8 m + 64 bytes).
+    replicate=True -- every rank also receives the other ranks' blocks (one at a time) and keeps
+    the whole matrix; only the pricing is split and the records are their 64-byte headers."""
     begin, end = col_range(cols, rank, world)
     t_gen = time.perf_counter()
     a, b, c = core.gen_dense_lp_block(seed, rows, cols, begin, end)
@@ -117,14 +123,13 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
              "tree": core.PRICE_TREE}[price_name]
     # poll interval 50 divides the default warm-up and step counts: no partial batches
-    # The matrix fits one GPU many times over (config 5: 17 GB of 288): every rank keeps all of it
-    # and only the pricing is split, so the all-gathers carry 64-byte headers instead of columns.
-    # The other ranks' blocks are generated and uploaded one at a time (host peak: two blocks).
     solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price,
-                           profile=1 << _ffi.K_PRICE, poll_interval=50, replicate=True)
+                           profile=1 << _ffi.K_PRICE, poll_interval=50, replicate=replicate)
     try:
         del a, lp
-        for other in range(world):
+        # replicated: the other ranks' blocks are generated and uploaded one at a time (host peak:
+        # two blocks)
+        for other in range(world if replicate else 0):
             if other != rank:
                 ob, oe = col_range(cols, other, world)
                 blk, _, _ = core.gen_dense_lp_block(seed, rows, cols, ob, oe)
@@ -196,7 +201,10 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
             "numerics": "fast", "price_kernel": price_name,
             "status_after_timed_region": status, "requested_steps": steps,
             "exchanges_per_iteration": 2, "record_bytes": record_bytes,
-            "matrix": "replicated on every rank (pricing split by column block)",
+            "matrix": ("replicated on every rank (pricing split by column block; 64-byte records)"
+                       if replicate else
+                       "partitioned by column block (a rank holds its block only; the entering "
+                       "column travels in the exchange records)"),
             "collective": "ncclAllGather (RCCL) of one record per rank",
             "nranks_ncclCommCount": nranks,
             "lp_generation_s": round(t_gen, 3),
@@ -231,18 +239,35 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
     # gloo: bootstrap (ncclUniqueId) + barriers only; a rank that dies must not hang the others
     dist.init_process_group("gloo", rank=rank, world_size=world,
                             timeout=datetime.timedelta(seconds=600))
+    # `value`: the PARTITIONED storage mode, the one BASELINE.json's north star states ("constraint
+    # matrix column-block partitioned across the 8 GPUs"); "replicated": the same workload with the
+    # whole matrix in every rank's HBM (it fits: 1 GB / 17 GB of 288) and header-only records.
+    sub = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "phases")
     out = _measure_sharded(dist, torch, args.rows, args.cols, args.seed, args.price, args.steps,
-                           args.warmup, rank, world, local_rank)
+                           args.warmup, rank, world, local_rank, replicate=False)
+    rep = _measure_sharded(dist, torch, args.rows, args.cols, args.seed, args.price, args.steps,
+                           args.warmup, rank, world, local_rank, replicate=True)
+    out["replicated"] = {k: rep[k] for k in sub}
     profiled = ("ROCP_TOOL_LIBRARIES" in os.environ
                 or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))
     if (args.rows == 8192 and args.cols == 16384 and not getattr(args, "no_secondary", False)
             and not profiled):
         # config 5: the LP the north star's 8-GPU target is quoted on (bench.py reports the same
-        # workload on one GPU under the same key)
+        # workload on one GPU under the same key), both storage modes again
         sec = _measure_sharded(dist, torch, 32768, 65536, 1005, "auto", 300, 50, rank, world,
-                               local_rank)
-        out["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step",
-                                                "config", "roofline", "phases")}
+                               local_rank, replicate=False)
+        out["secondary"] = {k: sec[k] for k in sub}
+        sec = _measure_sharded(dist, torch, 32768, 65536, 1005, "auto", 300, 50, rank, world,
+                               local_rank, replicate=True)
+        out["secondary"]["replicated"] = {k: sec[k] for k in sub}
+    if rank == 0 and not getattr(args, "no_cpu_baseline", False):
+        # the reference's algorithm on this box's host, one core, while the other ranks wait at the
+        # barrier below (bench.py: cpu_baseline)
+        import bench
+
+        out["cpu_baseline"] = bench.cpu_baseline(args.cpu_sample_rows, 2 * args.cpu_sample_rows, 1002,
+                                                 args.cpu_sample_pivots, args.rows)
+    dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -213,6 +213,17 @@ static void pivot_vec(double *data, const double *delta, int64_t len, int64_t in
     }
 }
 
+/* The factorisation the iteration calls.  The default is the literal restatement above; the
+ * twin library libdzg_oracle_blocked.so is this file compiled with
+ * -DORA_LU=ora_lu_factorize_blocked (dzg_oracle_blocked.c: the same operations on every element
+ * in the same order, bit-equal factors, rearranged for the cache and for several cores) and only
+ * writes pivot-log fixtures at sizes where the literal loop needs minutes per pivot. */
+#ifndef ORA_LU
+#define ORA_LU ora_lu_factorize
+#else
+void ORA_LU(double *a, int64_t n, int64_t *p);
+#endif
+
 /* Workspace for one solve */
 typedef struct {
     double *bm;    /* m*m  basis matrix, row-major: B[r][c] = A[r][basis[c]] */
@@ -238,7 +249,7 @@ static void solve_for_dx(const ora_simplex *s, ora_work *w, int64_t j)
 {
     gather_basis(s, w->bm); /* basis_matrix.clone().to_dense() */
     ora_csc_column(s->m, s->col_ptr, s->row_idx, s->val, j, w->dx);
-    ora_lu_factorize(w->bm, s->m, w->p);
+    ORA_LU(w->bm, s->m, w->p);
     ora_lu_solve(w->bm, s->m, w->p, w->dx);
 }
 
@@ -250,7 +261,7 @@ static void solve_for_dz(const ora_simplex *s, ora_work *w, int64_t pos)
     ora_matrix_t(w->bm, m, m, w->bt); /* .to_dense().t() */
     for (int64_t i = 0; i < m; ++i) w->v[i] = 0.0;
     w->v[pos] = 1.0;
-    ora_lu_factorize(w->bt, m, w->p); /* a second, independent LU (App. A.4) */
+    ORA_LU(w->bt, m, w->p); /* a second, independent LU (App. A.4) */
     ora_lu_solve(w->bt, m, w->p, w->v);
     ora_csc_neg_t_dot(s->col_ptr, s->row_idx, s->val, s->nonbasis, s->n - m, w->v, w->dz);
 }

@@ -85,6 +85,36 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_BLOCKED_PATH = os.path.join(_HERE, "libdzg_oracle_blocked.so")
+_blocked = None
+
+
+def blocked_lib() -> C.CDLL:
+    """The twin library: the same restatement with Matrix::factorize applied block by block on
+    several cores (dzg_oracle_blocked.c: same operations per element in the same order, bit-equal
+    factors -- tests/test_oracle_kats.py).  For pivot-log fixtures at benchmark sizes only; the
+    literal library stays the arbiter and the CPU baseline."""
+    global _blocked
+    if _blocked is None:
+        srcs = [os.path.join(_HERE, f) for f in ("dzg_oracle.c", "dzg_oracle_blocked.c", "dzg_oracle.h")]
+        if (not os.path.exists(_BLOCKED_PATH)
+                or os.path.getmtime(_BLOCKED_PATH) < max(os.path.getmtime(f) for f in srcs)):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libdzg_oracle_blocked.so"])
+        _blocked = C.CDLL(_BLOCKED_PATH)
+        _blocked.ora_simplex_solve.restype = C.c_int
+        _blocked.ora_objective_value.restype = C.c_double
+    return _blocked
+
+
+def lu_factorize_blocked(a: np.ndarray):
+    """ora_lu_factorize_blocked: must equal lu_factorize bit for bit."""
+    a = _f64(a).copy()
+    n = a.shape[0]
+    p = np.zeros(max(n - 1, 1), dtype=np.int64)
+    blocked_lib().ora_lu_factorize_blocked(_p(a), C.c_int64(n), _p(p))
+    return a, p[: max(n - 1, 0)]
+
+
 def _p(a: np.ndarray) -> C.c_void_p:
     return C.c_void_p(a.ctypes.data)
 
@@ -227,8 +257,8 @@ def stdform_from_dense(a: np.ndarray, b: np.ndarray, c: np.ndarray,
                    z=-_f64(c))
 
 
-def simplex_solve(sf: StdForm, max_iter: int = 1_000_000, log_cap: int | None = None
-                  ) -> SolveResult:
+def simplex_solve(sf: StdForm, max_iter: int = 1_000_000, log_cap: int | None = None,
+                  blocked: bool = False) -> SolveResult:
     m, n = sf.m, sf.n
     q = n - m
     basis, nonbasis = _i64(sf.basis).copy(), _i64(sf.nonbasis).copy()
@@ -248,8 +278,9 @@ def simplex_solve(sf: StdForm, max_iter: int = 1_000_000, log_cap: int | None = 
     cap = int(log_cap if log_cap is not None else min(max_iter, 4_000_000))
     log = (_Pivot * max(cap, 1))()
     iters = C.c_int64(0)
-    status = lib().ora_simplex_solve(C.byref(st), C.c_int64(max_iter), C.byref(iters), log,
-                                     C.c_int64(cap))
+    the_lib = blocked_lib() if blocked else lib()
+    status = the_lib.ora_simplex_solve(C.byref(st), C.c_int64(max_iter), C.byref(iters), log,
+                                       C.c_int64(cap))
     k = min(iters.value, cap)
     pivots = [(log[i].kind, log[i].entering, log[i].leaving, log[i].mu) for i in range(k)]
     obj = float(lib().ora_objective_value(C.byref(st))) if m >= 0 else float("nan")

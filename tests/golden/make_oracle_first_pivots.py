@@ -9,8 +9,14 @@ every pivot: an interrupted run keeps what it has.  Each record is what
 src/simplex.rs:274-306,308-330 decides -- (kind, entering, leaving) -- with mu* of that
 iteration and the seconds of CPU the pivot took on one core of the machine that ran this.
 
-  python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots
+  python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots [--blocked]
   (BASELINE config 3: 1003 8192 16384 8  -- about 6.5 minutes per pivot)
+
+--blocked: the twin library (oracle/dzg_oracle_blocked.c: Matrix::factorize applied block by
+block on several cores, the same operations per element in the same order -- bit-equal factors,
+tests/test_oracle_kats.py), some 20 s per pivot at 8192 rows; the file is then called
+oracle_blocked_pivots_<seed>_<m>x<ns>.json and says so.  The literal run's pivots are the check
+on it: both files exist for config 3 and tests/test_oracle_kats.py compares them.
 """
 import ctypes as C
 import json
@@ -27,7 +33,10 @@ from oracle import oracle as ora  # noqa: E402
 
 if __name__ == "__main__":
     seed, m, ns, pivots = (int(v) for v in sys.argv[1:5])
-    path = os.path.join(ROOT, "tests", "golden", f"oracle_first_pivots_{seed}_{m}x{ns}.json")
+    blocked = "--blocked" in sys.argv
+    the_lib = ora.blocked_lib() if blocked else ora.lib()
+    path = os.path.join(ROOT, "tests", "golden",
+                        f"oracle_{'blocked' if blocked else 'first'}_pivots_{seed}_{m}x{ns}.json")
     a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
     sf = ora.stdform_from_dense(a, b, c)
     del a
@@ -39,13 +48,14 @@ if __name__ == "__main__":
     st = ora._Simplex(m, n, ora._p(col_ptr), ora._p(row_idx), ora._p(val), ora._p(cc), float(sf.constant),
                       ora._p(basis), ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
     out = {"seed": seed, "m": m, "n_struct": ns, "generator": "G1 (dantzig_amd.core.gen_dense_lp)",
-           "source": "oracle/dzg_oracle.c, one ora_simplex_solve(max_iter=1) call per pivot",
+           "source": ("oracle/dzg_oracle.c + dzg_oracle_blocked.c (libdzg_oracle_blocked.so)" if blocked
+                      else "oracle/dzg_oracle.c") + ", one ora_simplex_solve(max_iter=1) call per pivot",
            "kind": [], "entering": [], "leaving": [], "mu": [], "seconds_per_pivot": []}
     log = (ora._Pivot * 1)()
     for k in range(pivots):
         iters = C.c_int64(0)
         t0 = time.perf_counter()
-        status = ora.lib().ora_simplex_solve(C.byref(st), C.c_int64(1), C.byref(iters), log, C.c_int64(1))
+        status = the_lib.ora_simplex_solve(C.byref(st), C.c_int64(1), C.byref(iters), log, C.c_int64(1))
         dt = time.perf_counter() - t0
         if iters.value != 1:
             out["status_after"] = ora.STATUS[status]

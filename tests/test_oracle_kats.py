@@ -178,3 +178,85 @@ def test_integer_lp_fixture_is_the_oracle():
         r = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=fx["cap"])
         assert (r.status, r.iterations, log_digest(r.pivots)) == (case["status"], case["pivots"],
                                                                   case["sha256"])
+
+
+# ------------------------------------------------------------------ the blocked twin of Matrix::factorize
+def _bits_equal(x, y):
+    x, y = np.asarray(x, float), np.asarray(y, float)
+    return x.shape == y.shape and bool(np.all((x.view(np.uint64) == y.view(np.uint64))
+                                              | (np.isnan(x) & np.isnan(y))))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 33, 63, 64, 65, 66, 97, 128, 129, 130, 200, 257, 500, 777])
+def test_blocked_lu_equals_the_literal_restatement_bit_for_bit(n, monkeypatch):
+    """oracle/dzg_oracle_blocked.c applies Matrix::factorize (src/linalg.rs:88-128) block by block
+    on several cores -- the same operations on every element in the same order.  Packed factors and
+    pivot vector must equal ora_lu_factorize's bit for bit: continuous data, small integers (exact
+    ties in the pivot search), all-zero columns inside and beyond the first panel (the silently
+    skipped zero pivot, :117), 0/1 matrices (singular more often than not: NaN/inf factors)."""
+    monkeypatch.setenv("OMP_NUM_THREADS", "3")
+    rng = np.random.default_rng(1000 + n)
+    for kind in range(4):
+        if kind == 0:
+            a = rng.uniform(-1, 1, (n, n))
+        elif kind == 1:
+            a = rng.integers(-2, 3, (n, n)).astype(np.float64)
+        elif kind == 2:
+            a = rng.uniform(-1, 1, (n, n))
+            if n > 3:
+                a[:, n // 3] = 0.0
+                a[:, min(n - 1, 70)] = 0.0
+        else:
+            a = (rng.uniform(size=(n, n)) < 0.1).astype(np.float64) + np.eye(n) * (rng.uniform(size=n) < 0.7)
+        lu0, p0 = ora.lu_factorize(a)
+        lu1, p1 = ora.lu_factorize_blocked(a)
+        assert p0.tolist() == p1.tolist(), (n, kind)
+        assert _bits_equal(lu0, lu1), (n, kind)
+
+
+def test_blocked_oracle_solve_equals_the_literal_one():
+    """The whole iteration through the twin library (only the factorisation differs): same pivot
+    log, mu, vectors and objective, bit for bit -- continuous and integer data."""
+    from dantzig_amd import core
+    from tests.lp_families import make_lp
+
+    a, b, c = core.gen_dense_lp(seed=31, m=300, n_struct=640)
+    cases = [(np.asarray(a), b, c, 150)] + [make_lp(s, 1 + s % 2, 40, 90) + (400,) for s in (5, 6, 7)]
+    for a, b, c, cap in cases:
+        sf = ora.stdform_from_dense(a, b, c)
+        r0 = ora.simplex_solve(sf, max_iter=cap)
+        r1 = ora.simplex_solve(sf, max_iter=cap, blocked=True)
+        assert r0.status == r1.status and r0.iterations == r1.iterations
+        assert r0.pivots == r1.pivots or _bits_equal([p[3] for p in r0.pivots], [p[3] for p in r1.pivots])
+        assert [p[:3] for p in r0.pivots] == [p[:3] for p in r1.pivots]
+        for name in ("x", "xbar", "z", "zbar"):
+            assert _bits_equal(getattr(r0, name), getattr(r1, name)), name
+
+
+def _first_pivot_fixture(kind, seed, m, ns):
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "golden", f"oracle_{kind}_pivots_{seed}_{m}x{ns}.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def test_pivot_fixtures_at_benchmark_size_agree():
+    """BASELINE config 3 (8192 x 16384, seed 1003): the LITERAL restatement's first pivots
+    (tests/golden/oracle_first_pivots_*.json, about 7 minutes of one core each) are the head of the
+    blocked twin's longer log (oracle_blocked_pivots_*.json, 20 s each) -- kind, entering, leaving
+    and every bit of mu.  Same for 4096 x 8192 where both exist."""
+    checked = 0
+    for seed, m, ns in [(1003, 8192, 16384), (1006, 4096, 8192)]:
+        lit, blk = _first_pivot_fixture("first", seed, m, ns), _first_pivot_fixture("blocked", seed, m, ns)
+        if lit is None or blk is None:
+            continue
+        n = min(len(lit["kind"]), len(blk["kind"]))
+        assert n >= 2
+        for key in ("kind", "entering", "leaving", "mu"):
+            assert lit[key][:n] == blk[key][:n], (m, key)
+        checked += 1
+    assert checked >= 1
