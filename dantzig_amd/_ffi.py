@@ -37,6 +37,7 @@ EXPORTS = [
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
     "dzg_gen_dense_lp_block", "dzg_solver_set_profile", "dzg_kernel_neg_t_dot_csc",
     "dzg_shard_comm_size", "dzg_solver_upload_columns", "dzg_debug_hold_cus", "dzg_debug_hold_wait",
+    "dzg_core_solve_full_csc",
 ]
 
 
@@ -157,6 +158,10 @@ def lib() -> C.CDLL:
         _lib.dzg_solver_stream.argtypes = [C.c_void_p]
         _lib.dzg_solver_refactor.argtypes = [C.c_void_p]
         _lib.dzg_solver_set_profile.argtypes = [C.c_void_p, C.c_int32]
+        _lib.dzg_core_solve_full_csc.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]
         _lib.dzg_debug_hold_cus.argtypes = [C.c_int32, C.c_int32, C.c_double]
         _lib.dzg_solver_upload_columns.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                                    C.c_int64]

@@ -265,6 +265,46 @@ def core_solve(lp: CoreLP, log_cap: int = 1 << 20, **opts) -> CoreResult:
             refactors=int(r.refactors), chain_fallbacks=int(r.chain_fallbacks))
 
 
+def core_solve_full_csc(m: int, n: int, col_ptr, row_idx, val, c, constant, basis, nonbasis, x, z,
+                        log_cap: int = 1 << 16, **opts) -> CoreResult:
+    """dzg_core_solve_full_csc: Level 1 on the reference's own `Simplex` fields -- ONE CSC over all n
+    columns, slack columns included, 64-bit indices (src/simplex.rs:84-112, src/linalg.rs:161-168).
+    The in/out arrays of the C call are copies here; the final state comes back in the result."""
+    _ffi.require_gpu()
+    q = n - m
+    col_ptr, row_idx, val, c = i64(col_ptr), i64(row_idx), f64(val), f64(c)
+    basis, nonbasis = i64(basis).copy(), i64(nonbasis).copy()
+    x, z = f64(x).copy(), f64(z).copy()
+    if len(row_idx) == 0:
+        row_idx, val = np.zeros(1, np.int64), np.zeros(1)
+    xbar, zbar = np.zeros(max(m, 1)), np.zeros(max(q, 1))
+    buf = (_ffi.Pivot * max(log_cap, 1))()
+    margins = np.full(max(log_cap, 1), np.inf)
+    r = _ffi.Result()
+    r.xbar, r.zbar = ptr(xbar), ptr(zbar)
+    r.log, r.log_cap, r.margins = C.cast(buf, C.c_void_p), log_cap, ptr(margins)
+    o = _ffi.default_opts(**opts)
+    rc = _ffi.lib().dzg_core_solve_full_csc(
+        int(m), int(n), ptr(col_ptr), ptr(row_idx), ptr(val), ptr(c), float(constant),
+        ptr(basis if m else np.zeros(1, np.int64)), ptr(nonbasis if q else np.zeros(1, np.int64)),
+        ptr(x if m else np.zeros(1)), ptr(z if q else np.zeros(1)), C.byref(o), C.byref(r))
+    _ffi.check(rc, "dzg_core_solve_full_csc")
+    cnt = int(min(r.iterations, log_cap))
+    arr = np.ctypeslib.as_array(buf)[:cnt]
+    pivots = list(zip(arr["kind"].tolist(), arr["entering"].tolist(), arr["leaving"].tolist(),
+                      arr["mu"].tolist()))
+    return CoreResult(
+        status=STATUS_NAMES.get(r.status, str(r.status)), status_code=r.status,
+        numerics="strict" if r.numerics_used == STRICT else "fast",
+        iterations=int(r.iterations), objective=float(r.objective),
+        basis=basis[:m], nonbasis=nonbasis[:q], x=x[:m], xbar=xbar[:m].copy(), z=z[:q],
+        zbar=zbar[:q].copy(), pivots=pivots, max_pivot_error=float(r.max_pivot_error),
+        near_ties=int(r.near_ties), first_near_tie=int(r.first_near_tie),
+        min_margin=float(r.min_margin), margins=margins[:cnt].copy(),
+        dense_columns=int(r.dense_columns), refactors=int(r.refactors),
+        chain_fallbacks=int(r.chain_fallbacks))
+
+
 # ------------------------------------------------------------------ synthetic LPs (SURVEY 8(d))
 def gen_dense_lp(seed: int, m: int, n_struct: int):
     """Generator G1.  Returns (A as an (m, n_struct) Fortran-ordered array, b, c)."""

@@ -1481,6 +1481,105 @@ extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result
     return rc;
 }
 
+// Level 1 on the fields of the reference's `Simplex` AS THEY ARE (src/simplex.rs:84-112): one
+// CscMatrix over all n columns, slack columns included (src/linalg.rs:161-168; usize indices),
+// b / n / x / z, the objective's coefficients and constant.  Simplex::solve becomes this one call.
+// The unit columns that the device never stores are found here: a column with exactly one stored
+// entry, equal to 1.0, is the slack of its row (scanned from the last column down, one per row --
+// Simplex::new puts the slacks last; any further unit column of a row stays an ordinary column).
+// The remaining columns go to the device dense or as CSC, whichever is smaller.
+extern "C" int dzg_core_solve_full_csc(int64_t m, int64_t n, const int64_t *col_ptr,
+                                       const int64_t *row_idx, const double *val, const double *c,
+                                       double constant, int64_t *basis, int64_t *nonbasis, double *x,
+                                       double *z, const dzg_opts *opts, dzg_result *res)
+{
+    if (!res) return fail(DZG_E_ARG, "res is NULL");
+    if (m < 0 || n < m || !col_ptr || (n > 0 && !c) || (m > 0 && (!basis || !x)) ||
+        (n > m && (!nonbasis || !z)))
+        return fail(DZG_E_ARG, "full_csc: sizes / NULL argument");
+    if (n >= (1ll << 31) - 64) return fail(DZG_E_ARG, "full_csc: index range");
+    if (col_ptr[0] != 0) return fail(DZG_E_ARG, "full_csc: col_ptr[0] != 0");
+    for (int64_t j = 0; j < n; ++j) {
+        if (col_ptr[j + 1] < col_ptr[j]) return fail(DZG_E_ARG, "full_csc: col_ptr not monotone");
+        for (int64_t e = col_ptr[j]; e < col_ptr[j + 1]; ++e)
+            if (!row_idx || !val || row_idx[e] < 0 || row_idx[e] >= m ||
+                (e > col_ptr[j] && row_idx[e] <= row_idx[e - 1]))
+                return fail(DZG_E_ARG, "full_csc: row_idx must ascend strictly inside a column");
+    }
+    std::vector<int64_t> var_col((size_t)(n ? n : 1), 0);
+    std::vector<char> row_has_slack((size_t)(m ? m : 1), 0), is_slack((size_t)(n ? n : 1), 0);
+    for (int64_t j = n - 1; j >= 0; --j) {
+        const int64_t e = col_ptr[j];
+        if (col_ptr[j + 1] - e == 1 && val[e] == 1.0 && !row_has_slack[(size_t)row_idx[e]]) {
+            row_has_slack[(size_t)row_idx[e]] = 1;
+            is_slack[(size_t)j] = 1;
+            var_col[(size_t)j] = -1 - row_idx[e];
+        }
+    }
+    int64_t ns = 0, nnz = 0;
+    for (int64_t j = 0; j < n; ++j)
+        if (!is_slack[(size_t)j]) {
+            var_col[(size_t)j] = ns++;
+            for (int64_t e = col_ptr[j]; e < col_ptr[j + 1]; ++e) nnz += val[e] != 0.0;
+        }
+    dzg_lp lp;
+    std::memset(&lp, 0, sizeof(lp));
+    lp.m = m; lp.n = n; lp.n_struct = ns;
+    lp.var_col = var_col.data();
+    lp.c = c; lp.constant = constant;
+    lp.basis = basis; lp.nonbasis = nonbasis; lp.x = x; lp.z = z;
+    // dense (8 m ns bytes) or CSC (12 bytes per entry + the CSR copy of the sparse-basis path)
+    const bool dense = ns > 0 && (double)nnz * 24.0 >= (double)m * (double)ns * 8.0;
+    std::vector<double> a, sval;
+    std::vector<int64_t> scp;
+    std::vector<int32_t> sri;
+    if (dense) {
+        a.assign((size_t)m * (size_t)ns, 0.0);
+        for (int64_t j = 0; j < n; ++j)
+            if (!is_slack[(size_t)j])
+                for (int64_t e = col_ptr[j]; e < col_ptr[j + 1]; ++e)
+                    a[(size_t)var_col[(size_t)j] * (size_t)m + (size_t)row_idx[e]] = val[e];
+        lp.a = a.data();
+        lp.lda = m;
+    } else if (ns > 0) {
+        scp.assign((size_t)ns + 1, 0);
+        sri.reserve((size_t)nnz);
+        sval.reserve((size_t)nnz);
+        for (int64_t j = 0; j < n; ++j)
+            if (!is_slack[(size_t)j]) {
+                for (int64_t e = col_ptr[j]; e < col_ptr[j + 1]; ++e)
+                    if (val[e] != 0.0) { // (the reference's CSC holds no explicit zeros, src/linalg.rs:261)
+                        sri.push_back((int32_t)row_idx[e]);
+                        sval.push_back(val[e]);
+                    }
+                scp[(size_t)var_col[(size_t)j] + 1] = (int64_t)sri.size();
+            }
+        if (sri.empty()) { sri.push_back(0); sval.push_back(0.0); }
+        lp.col_ptr = scp.data();
+        lp.row_idx = sri.data();
+        lp.val = sval.data();
+    }
+    // the final state lands in the caller's b / n / x / z, as Simplex::solve leaves it in `self`
+    const int64_t q = n - m;
+    std::vector<int64_t> ob, on;
+    std::vector<double> ox, oz;
+    dzg_result r = *res;
+    if (!r.basis) { ob.resize((size_t)(m ? m : 1)); r.basis = ob.data(); }
+    if (!r.nonbasis) { on.resize((size_t)(q ? q : 1)); r.nonbasis = on.data(); }
+    if (!r.x) { ox.resize((size_t)(m ? m : 1)); r.x = ox.data(); }
+    if (!r.z) { oz.resize((size_t)(q ? q : 1)); r.z = oz.data(); }
+    const int rc = dzg_core_solve(&lp, opts, &r);
+    if (rc < 0) return rc;
+    for (int64_t p = 0; p < m; ++p) { basis[p] = r.basis[p]; x[p] = r.x[p]; }
+    for (int64_t k = 0; k < q; ++k) { nonbasis[k] = r.nonbasis[k]; z[k] = r.z[k]; }
+    if (!res->basis) r.basis = nullptr;
+    if (!res->nonbasis) r.nonbasis = nullptr;
+    if (!res->x) r.x = nullptr;
+    if (!res->z) r.z = nullptr;
+    *res = r;
+    return rc;
+}
+
 // ---- single-function entry points for parity tests -------------------------------
 extern "C" int dzg_kernel_lu_solve(int64_t n, const double *a, const double *b, double *x_out,
                                    double *lu_out, int64_t *p_out, int32_t device)

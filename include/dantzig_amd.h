@@ -187,6 +187,13 @@ enum {
     DZG_K_XCHG1, DZG_K_XCHG2,
     DZG_K_COUNT
 };
+/* Mirrors of dzg_result in other languages write this number out (the Rust
+ * `[c_double; DZG_K_COUNT]`, dantzig_amd/_ffi.py): adding a class is an ABI change. */
+#ifdef __cplusplus
+static_assert(DZG_K_COUNT == 10, "dzg_result.kernel_ms / kernel_launches have 10 entries");
+#else
+_Static_assert(DZG_K_COUNT == 10, "dzg_result.kernel_ms / kernel_launches have 10 entries");
+#endif
 
 typedef struct {
     int32_t status;          /* dzg_status                                              */
@@ -258,6 +265,25 @@ int dzg_solver_refactor(dzg_solver *s);
  * caller knows from which pivot on the path is no longer certified to be the reference's. */
 #define DZG_AUTO_STRICT_RESTART_ROWS 2048
 int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result *res);
+
+/* The same on the fields of the reference's `Simplex` exactly as Rust holds them
+ * (src/simplex.rs:84-112), so that Simplex::solve (:332-343) becomes ONE call with no
+ * reshaping on the Rust side:
+ *   constraints: CscMatrix  ->  m = nrows, n = ncols, col_ptr[n+1], row_idx[nnz], val = data[nnz]
+ *                               over ALL n columns, slack columns included (src/linalg.rs:161-168;
+ *                               Vec<usize> is 64-bit on the reference's targets: pass .as_ptr())
+ *   objective               ->  c = coefficients[n], constant
+ *   b, n, x, z              ->  basis[m], nonbasis[n-m], x[m], z[n-m]   (x_bar = z_bar = 1, :203-204)
+ * The library finds the unit slack columns itself (a column whose only stored entry is 1.0; one per
+ * row, scanned from the last column down -- Simplex::new puts them last, :188-201) and keeps the
+ * other columns dense or CSC on the device, whichever is smaller.  IN/OUT: on return (status >= 0)
+ * basis / nonbasis / x / z hold the final state, as Simplex::solve leaves it in `self`; `res` is
+ * filled like dzg_core_solve fills it (its optional buffers may be NULL).  Numerics: as
+ * dzg_core_solve (opts == NULL: AUTO). */
+int dzg_core_solve_full_csc(int64_t m, int64_t n, const int64_t *col_ptr, const int64_t *row_idx,
+                            const double *val, const double *c, double constant, int64_t *basis,
+                            int64_t *nonbasis, double *x, double *z, const dzg_opts *opts,
+                            dzg_result *res);
 
 /* ---- Level 2: replaces dantzig.rust.solve (src/lib.rs:16-27) ---------------------- */
 

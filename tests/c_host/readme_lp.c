@@ -6,7 +6,10 @@
  * the way the PyO3 layer would hand it over (Level 2: objective negated for the maximising
  * core, `==` lowered to two opposite inequalities, python-source/dantzig/optimize.py:114-117,
  * model.py:350-375), then a small G1 LP through Level 1 (dzg_core_solve on the post-Simplex::new
- * state).  Output: one line per solve, parsed by tests/test_abi.py.
+ * state), then the README LP once more through dzg_core_solve_full_csc on the fields of the
+ * reference's `Simplex` exactly as Rust holds them (src/simplex.rs:84-112: ONE CSC over all
+ * columns, slacks included, 64-bit indices) -- the call INTEGRATION.md puts into Simplex::solve.
+ * Output: one line per solve, parsed by tests/test_abi.py.
  * Exit code 0 = both solved; 3 = the library reported DZG_E_DEVICE (no GPU: loud failure). */
 #include <stdio.h>
 #include <stdlib.h>
@@ -86,6 +89,68 @@ static int level1(void)
     return res.status;
 }
 
+/* The README LP after Simplex::new, written the way the reference stores it: the host-only
+ * builder gives the dense structural block + column codes; one CSC over all n columns (rows
+ * ascending, no explicit zeros, unit slack columns stored like any other) is assembled from it. */
+static int level1_full_csc(void)
+{
+    const int32_t has_lb[3] = {1, 1, 1}, has_ub[3] = {0, 0, 0};
+    const double lb[3] = {0.0, 0.0, 0.0}, ub[3] = {0.0, 0.0, 0.0};
+    const int64_t obj_var[3] = {0, 1, 2};
+    const double obj_coef[3] = {-1.0, -1.0, 1.0};
+    const int64_t con_ptr[3] = {0, 3, 6};
+    const int64_t con_var[6] = {0, 1, 2, 0, 1, 2};
+    const double con_coef[6] = {1.0, 1.0, 1.0, -1.0, -1.0, -1.0};
+    const double con_b[2] = {1.0, -1.0};
+    dzg_model model = {3, has_lb, has_ub, lb, ub, 3, obj_var, obj_coef, 0.0,
+                       2, con_ptr, con_var, con_coef, con_b};
+    dzg_stdform sf = {0};
+    if (dzg_build_standard_form(&model, &sf) != 0) return DZG_E_ARG; /* sizes */
+    enum { CAP = 64 };
+    static double a[CAP * CAP], c[CAP], x[CAP], z[CAP], val[CAP * CAP];
+    static int64_t var_col[CAP], basis[CAP], nonbasis[CAP], pos_var[3], neg_var[3];
+    static int64_t col_ptr[CAP + 1], row_idx[CAP * CAP];
+    if (sf.n > CAP || sf.lda > CAP) return DZG_E_ARG;
+    sf.a = a; sf.var_col = var_col; sf.c = c; sf.basis = basis; sf.nonbasis = nonbasis;
+    sf.x = x; sf.z = z; sf.pos_var = pos_var; sf.neg_var = neg_var;
+    if (dzg_build_standard_form(&model, &sf) != 0) return DZG_E_ARG;
+    int64_t nnz = 0;
+    col_ptr[0] = 0;
+    for (int64_t v = 0; v < sf.n; ++v) {
+        if (var_col[v] >= 0) {
+            for (int64_t i = 0; i < sf.m; ++i) {
+                const double e = a[var_col[v] * sf.lda + i];
+                if (e != 0.0) { row_idx[nnz] = i; val[nnz] = e; ++nnz; }
+            }
+        } else {
+            row_idx[nnz] = -1 - var_col[v];
+            val[nnz] = 1.0;
+            ++nnz;
+        }
+        col_ptr[v + 1] = nnz;
+    }
+    dzg_result res = {0};
+    dzg_opts opts;
+    dzg_opts_default(&opts);
+    const int rc = dzg_core_solve_full_csc(sf.m, sf.n, col_ptr, row_idx, val, c, sf.constant, basis,
+                                           nonbasis, x, z, &opts, &res);
+    if (rc < 0) {
+        fprintf(stderr, "dzg_core_solve_full_csc: %s (%s)\n", dzg_status_str(rc), dzg_last_error());
+        return rc;
+    }
+    /* Simplex::solution (src/simplex.rs:354-371) on the state that came back in place */
+    double user[3] = {0.0, 0.0, 0.0};
+    for (int u = 0; u < 3; ++u)
+        for (int64_t p = 0; p < sf.m; ++p) {
+            if (basis[p] == pos_var[u]) user[u] += x[p];
+            if (basis[p] == neg_var[u]) user[u] -= x[p];
+        }
+    printf("fullcsc status=%s iterations=%lld objective=%.17g x=%.17g y=%.17g z=%.17g m=%lld n=%lld nnz=%lld\n",
+           dzg_status_str(res.status), (long long)res.iterations, -res.objective, user[0], user[1],
+           user[2], (long long)sf.m, (long long)sf.n, (long long)nnz);
+    return res.status;
+}
+
 int main(void)
 {
     printf("abi %d devices %d\n", dzg_abi_version(), dzg_device_count());
@@ -94,5 +159,8 @@ int main(void)
     if (r2 != DZG_OPTIMAL) return 1;
     const int r1 = level1();
     if (r1 == DZG_E_DEVICE) return 3;
-    return r1 == DZG_OPTIMAL ? 0 : 1;
+    if (r1 != DZG_OPTIMAL) return 1;
+    const int r3 = level1_full_csc();
+    if (r3 == DZG_E_DEVICE) return 3;
+    return r3 == DZG_OPTIMAL ? 0 : 1;
 }

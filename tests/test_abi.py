@@ -68,6 +68,29 @@ def test_struct_layouts_match_the_header(tmp_path):
             assert int(got[f"{cname}.{field}"]) == getattr(mirror, field).offset, f"{cname}.{field}"
 
 
+def test_rust_mirror_in_integration_md_matches_the_header():
+    """INTEGRATION.md's `#[repr(C)]` mirrors are hand-written: their array length and field order are
+    tied to the header here (the header itself pins DZG_K_COUNT with a static assertion)."""
+    import re
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert f"pub const DZG_K_COUNT: usize = {_ffi.K_COUNT};" in text
+    header = open(os.path.join(ROOT, "include", "dantzig_amd.h")).read()
+    assert "_Static_assert(DZG_K_COUNT == 10" in header and _ffi.K_COUNT == 10
+    for rust_name, mirror in (("DzgResult", _ffi.Result), ("DzgOpts", _ffi.Opts)):
+        body = text[text.index(f"pub struct {rust_name} {{"):]
+        body = body[:body.index("\n}")]
+        fields = re.findall(r"pub (\w+):", body)
+        assert fields == [name for name, _ in mirror._fields_], rust_name
+    # the one call of seam A takes the arguments in the header's order
+    sig = header[header.index("int dzg_core_solve_full_csc("):]
+    sig = sig[:sig.index(";")]
+    c_args = re.findall(r"(\w+)(?:,|\))", sig)
+    rust = text[text.index("pub fn dzg_core_solve_full_csc("):]
+    rust = rust[:rust.index("-> c_int")]
+    assert re.findall(r"(\w+):", rust) == c_args
+
+
 def test_generators_are_deterministic_host_code():
     a1, b1, c1 = core.gen_dense_lp(seed=5, m=7, n_struct=11)
     a2, b2, c2 = core.gen_dense_lp(seed=5, m=7, n_struct=11)
@@ -199,7 +222,7 @@ def test_plain_c_host_solves_the_readme_lp(tmp_path):
     run = _build_c_host(tmp_path)
     assert run.returncode == 0, run.stderr
     lines = {ln.split()[0]: dict(kv.split("=") for kv in ln.split()[1:])
-             for ln in run.stdout.splitlines() if ln.startswith("level")}
+             for ln in run.stdout.splitlines() if ln.startswith(("level", "fullcsc"))}
     l2 = lines["level2"]
     assert l2["status"] == "optimal"
     assert (float(l2["objective"]), float(l2["x"]), float(l2["y"]), float(l2["z"])) == (-1.0, 0.0, 0.0, 1.0)
@@ -211,6 +234,11 @@ def test_plain_c_host_solves_the_readme_lp(tmp_path):
     assert float(l1["objective"]) == want.objective           # STRICT: bit-identical
     k, e, l, _ = want.pivots[0]
     assert l1["first_pivot"] == f"{k}:{e}:{l}"
+    # the README LP through dzg_core_solve_full_csc, in the reference's own storage: same optimum,
+    # same pivot count as Level 2 took
+    fc = lines["fullcsc"]
+    assert fc["status"] == "optimal" and fc["iterations"] == l2["iterations"]
+    assert (float(fc["objective"]), float(fc["x"]), float(fc["y"]), float(fc["z"])) == (-1.0, 0.0, 0.0, 1.0)
 
 
 def test_reference_package_name_resolves_to_this_implementation():

@@ -299,6 +299,58 @@ def test_reference_solver_kats_through_level2(kats, name):
             assert res.iterations == want.iterations
 
 
+@pytest.mark.parametrize("name", _names("solver"))
+def test_reference_solver_kats_through_the_full_csc_entry(core, kats, name):
+    """dzg_core_solve_full_csc takes `Simplex`'s fields as the reference holds them
+    (src/simplex.rs:84-112): ONE CscMatrix over all n columns, slack columns included, 64-bit
+    indices, b / n / x / z -- here exactly what the oracle's Simplex::new leaves (STRICT: pivot
+    log, mu, vectors and objective bit for bit; the final b / n / x / z come back in place)."""
+    k = next(s for s in kats["solver"] if s["name"] == name)
+    sf = ora.build_standard_form(k["model"])
+    want = ora.simplex_solve(sf)
+    if sf.m == 0:
+        pytest.skip("no rows: the reference underflows n - 1 (covered by the edge-shape tests)")
+    got = core.core_solve_full_csc(sf.m, sf.n, sf.col_ptr, sf.row_idx, sf.val, sf.c, sf.constant,
+                                   sf.basis, sf.nonbasis, sf.x, sf.z, numerics=core.STRICT)
+    assert got.status == want.status == k["expect"]["status"]
+    assert _log(got) == _log(want)
+    assert _same_bits([p[3] for p in got.pivots], [p[3] for p in want.pivots])
+    assert got.basis.tolist() == want.basis.tolist() and got.nonbasis.tolist() == want.nonbasis.tolist()
+    for name_ in ("x", "xbar", "z", "zbar"):
+        assert _same_bits(getattr(got, name_), getattr(want, name_)), name_
+    if want.status == "optimal":
+        assert got.objective == want.objective
+
+
+def test_full_csc_entry_on_dense_and_sparse_lps(core):
+    """The same entry on G1 / G2 LPs written the reference's way ([A | I] in one CSC): the dense one
+    goes to the device as a dense block, the sparse one stays CSC (sparse-basis path in FAST);
+    a structural column that happens to be a unit vector is handled either way."""
+    rng = np.random.default_rng(4)
+    a, b, c = core.gen_dense_lp(seed=61, m=40, n_struct=70)
+    a = np.array(a)
+    a[:, 5] = 0.0
+    a[7, 5] = 1.0                      # a structural unit column in a row that also has a slack
+    cp, ri, val, bs, cs = core.gen_sparse_lp(62, 300, 700, 5)
+    dense_sparse = np.zeros((300, 700))
+    for j in range(700):
+        dense_sparse[ri[cp[j]:cp[j + 1]], j] = val[cp[j]:cp[j + 1]]
+    for a_, b_, c_, numerics in [(a, b, c, core.STRICT), (a, b, c, core.FAST),
+                                 (dense_sparse, bs, cs, core.FAST)]:
+        sf = ora.stdform_from_dense(a_, b_, c_)
+        want = ora.simplex_solve(sf)
+        got = core.core_solve_full_csc(sf.m, sf.n, sf.col_ptr, sf.row_idx, sf.val, sf.c, sf.constant,
+                                       sf.basis, sf.nonbasis, sf.x, sf.z, numerics=numerics)
+        assert got.status == want.status == "optimal"
+        assert _log(got) == _log(want)
+        assert got.basis.tolist() == want.basis.tolist()
+        if numerics == core.STRICT:
+            assert _same_bits(got.x, want.x) and got.objective == want.objective
+        else:
+            assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+    del rng
+
+
 # ------------------------------------------------------------------ independent optimum (HiGHS)
 def _highs_cases():
     import json
