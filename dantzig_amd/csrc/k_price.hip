@@ -17,21 +17,38 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
 {
     const dim3 grid(DZG_PRICE_TREE_BLOCKS), block(256);
     const int per_wave = (ncols + 4 * DZG_PRICE_TREE_BLOCKS - 1) / (4 * DZG_PRICE_TREE_BLOCKS);
-    // 15-16 columns per wave: two full passes of 8 with 2-KiB visits (160.8 us against 162.7 at 8192
-    // rows); 9-14: the second pass would be half empty -- one pass of 16 (at 11 columns per wave,
-    // k = 4 920: 125.8 us against 133.2; profiles/r02_price_shape_deep_in_the_solve.txt)
-    if (per_wave > 14)
-        hipLaunchKernelGGL((k_price_tree<8, 2, 2>), grid, block, 0, st, PRICE_ARGS, pcode);
-    else if (per_wave > 8)
-        hipLaunchKernelGGL((k_price_tree<16, 2>), grid, block, 0, st, PRICE_ARGS, pcode);
-    else if (per_wave > 4)
-        hipLaunchKernelGGL((k_price_tree<8, 4>), grid, block, 0, st, PRICE_ARGS, pcode);
-    else if (per_wave > 2)
-        hipLaunchKernelGGL((k_price_tree<4, 8>), grid, block, 0, st, PRICE_ARGS, pcode);
-    else if (per_wave > 1)
-        hipLaunchKernelGGL((k_price_tree<2, 16>), grid, block, 0, st, PRICE_ARGS, pcode);
-    else
-        hipLaunchKernelGGL((k_price_tree<1, 32>), grid, block, 0, st, PRICE_ARGS, pcode);
+    // Columns per wave and pass = what a wave actually gets (a load slot of a pass that has no
+    // column re-reads the wave's last one: L2 traffic and issue slots for nothing -- one pass of
+    // 16 with 12 columns per wave, 12 324 nonbasic structural columns deep in the benchmark solve,
+    // streamed at 5.9 TB/s against 6.6 with every slot used, profiles/r03_deep_regime_*).  More
+    // than 16 columns: the fewest passes of equal width.  Tiles in flight follow the width so that
+    // a wave keeps 26-36 KB on its way.  The sums do not depend on any of this (only on m).
+    const int passes = (per_wave + 15) / 16;
+    const int cw = passes > 0 ? (per_wave + passes - 1) / passes : 1;
+#define TREE(CW, DEPTH, TP)                                                                          \
+    hipLaunchKernelGGL((k_price_tree<CW, DEPTH, TP>), grid, block, 0, st, PRICE_ARGS, pcode)
+    // (15-16 columns per wave in two passes of 8 with 2-KiB visits: 160.8 us against 162.7 at 8192
+    // rows, profiles/r02_price_microbench_adjacent_tiles.txt)
+    if (passes == 2 && cw == 8) { TREE(8, 2, 2); return; }
+    switch (cw) {
+    case 16: TREE(16, 2, 1); break;
+    case 15: TREE(15, 2, 1); break;
+    case 14: TREE(14, 2, 1); break;
+    case 13: TREE(13, 2, 1); break;
+    case 12: TREE(12, 3, 1); break;
+    case 11: TREE(11, 3, 1); break;
+    case 10: TREE(10, 3, 1); break;
+    case 9: TREE(9, 3, 1); break;
+    case 8: TREE(8, 4, 1); break;
+    case 7: TREE(7, 4, 1); break;
+    case 6: TREE(6, 5, 1); break;
+    case 5: TREE(5, 6, 1); break;
+    case 4: TREE(4, 8, 1); break;
+    case 3: TREE(3, 10, 1); break;
+    case 2: TREE(2, 16, 1); break;
+    default: TREE(1, 32, 1); break;
+    }
+#undef TREE
 }
 
 static void launch(int kernel, int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,

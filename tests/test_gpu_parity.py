@@ -815,15 +815,17 @@ def test_continuous_lp_is_not_flagged(core):
 # ------------------------------------------------------------------ k_price_tree
 def test_tree_pricing_does_not_depend_on_its_launch_shape(core):
     """k_price_tree's sums depend only on m: the same column priced among 5, 700, 3000 or all
-    9000 columns (1, 2, 4, 8, 16 columns per wave; 32 ... 2 tiles in flight) gives the same bits --
-    which is what makes a column-sharded solve take the pivots of the unsharded one."""
+    17000 columns -- every pass width from 1 to 16 columns per wave (32 ... 2 tiles in flight), one
+    pass and two -- gives the same bits, which is what makes a column-sharded solve take the pivots
+    of the unsharded one."""
     rng = np.random.default_rng(5)
-    m, ns = 1000, 9000
+    m, ns = 1000, 17000
     a = rng.uniform(-1, 1, (m, ns))
     v = rng.uniform(-1, 1, m)
-    full = core.neg_t_dot(a, np.arange(ns), v, kernel=core.PRICE_TREE)
+    full = core.neg_t_dot(a, np.arange(ns), v, kernel=core.PRICE_TREE)          # 17 per wave: 2 x 9
     assert np.allclose(full, -(a.T @ v), rtol=0, atol=1e-12)
-    for count in (5, 700, 1500, 3000, 5000):
+    counts = [5, 700] + [1024 * w - 300 for w in range(2, 17)] + [1024 * 16, 16000]
+    for count in counts:
         cols = rng.choice(ns, count, replace=False)
         part = core.neg_t_dot(a, cols, v, kernel=core.PRICE_TREE)
         assert_bit_equal(part, full[cols], f"{count} columns")
