@@ -266,7 +266,7 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
         import bench
 
         out["cpu_baseline"] = bench.cpu_baseline(args.cpu_sample_rows, 2 * args.cpu_sample_rows, 1002,
-                                                 args.cpu_sample_pivots, args.rows)
+                                                 args.cpu_sample_pivots, args.rows, args.cpu_anchor_rows)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
