@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F64_PEAK_TFLOPS = 46.9  # v_mfma_f64_16x16x4_f64, measured: profiles/r02_mfma_f64_peak_microbench.txt
 
 
 # The reference's algorithm (a dense LU of B and of B^T from scratch in every iteration) is far
@@ -276,7 +277,8 @@ SEVEN_LAUNCHES = False  # --seven-launches: the FAST iteration as seven kernels 
 
 
 def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, warmup,
-            late_pivots: int = 0, deep_pivots: int = 0, whole_solve: bool = False) -> dict:
+            late_pivots: int = 0, deep_pivots: int = 0, whole_solve: bool = False,
+            mfma_block: bool = False) -> dict:
     """One workload on one GPU: generate, upload (untimed), `warmup` pivots, then `steps` timed;
     with late_pivots > 0 a second timed region deep in the same solve (see _late_regime)."""
     from dantzig_amd import _ffi, core
@@ -300,7 +302,7 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                          profile=1 << _ffi.K_PRICE, poll_interval=50,
                          seven_launches=1 if SEVEN_LAUNCHES else 0)
     t_up = time.perf_counter() - t_up
-    late = deep = whole = None
+    late = deep = whole = mfma = None
     try:
         status = solver.run(warmup) if warmup > 0 else "iter_limit"
         r0 = solver.result(log=False)
@@ -315,6 +317,28 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                 # the same solve deeper still: the basis inverse is several thousand columns wide
                 # and FTRAN streams as many bytes as the pricing pass has shed
                 deep = _late_regime(solver, solver.result(log=False), steps, deep_pivots, kernel)
+        if mfma_block and numerics_name == "fast" and sparse_per_col <= 0 and status == "iter_limit":
+            # the refactorisation's GEMM side against the fp64 MFMA peak -- ONE timed
+            # dzg_solver_refactor at the deepest regime reached above (blocked LU with partial
+            # pivoting of the k x k structural block, the explicit inverse, the slack rows: all but
+            # the panels are MFMA GEMMs, csrc/k_refactor.hip).  After every timed region.
+            rk = solver.result(log=False)
+            k = rk.dense_columns
+            if k >= 256:
+                tr = time.perf_counter()
+                solver.refactor()
+                tr = time.perf_counter() - tr
+                flops = 2.0 * k ** 3 + 2.0 * (rows - k) * k ** 2
+                mfma = {"bound": "mfma", "what": "dzg_solver_refactor (k_refactor.hip) at k = %d of m = %d" % (k, rows),
+                        "k": k, "seconds": tr, "flops_model": "2 k^3 (LU + forward and backward substitution of the identity) + 2 (m - k) k^2 (slack rows)",
+                        "achieved": flops / tr / 1e12, "unit": "TFLOP/s", "peak": MFMA_F64_PEAK_TFLOPS,
+                        "frac": flops / tr / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                        "peak_note": "v_mfma_f64_16x16x4_f64 measured on this chip by tools/mfma_f64_peak.hip "
+                                     "(profiles/r02_mfma_f64_peak_microbench.txt); the datasheet's 78.6 is not "
+                                     "reached by that instruction",
+                        "MfmaUtil": None,
+                        "MfmaUtil_note": "per-kernel MFMA busy cycles: profiles/r01_pmc_mfma_summary.txt, "
+                                         "profiles/r03_refactor_kernel_stats.csv (rocprofv3, separate runs)"}
         if whole_solve and numerics_name == "fast":
             # the rest of the solve, to optimality (the untimed regime blocks above are part of the
             # same trajectory; pivots and seconds are those of this last stretch)
@@ -372,6 +396,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
         out["late"] = late
     if deep is not None:
         out["deep"] = deep
+    if mfma is not None:
+        out["mfma"] = mfma
     if whole is not None:
         out["whole_solve_remainder"] = whole
     return out
@@ -396,6 +422,8 @@ def main() -> int:
     ap.add_argument("--deep-pivots", type=int, default=150000,
                     help="a third timed region after this many pivots (default 150000: k ~ 4000 on the "
                          "benchmark LP, ~30 s untimed); 0 or --no-late = skip")
+    ap.add_argument("--no-mfma", action="store_true",
+                    help="skip the timed refactorisation (the \"mfma\" block) after the timed regions")
     ap.add_argument("--whole-solve", action="store_true",
                     help="after the timed regions run the solve to its end and report the stretch "
                          "(the benchmark LP: ~515 000 pivots, ~2 minutes)")
@@ -453,7 +481,8 @@ def main() -> int:
     deep_pivots = args.deep_pivots if (late_pivots > 0 and args.rows == 8192 and args.cols == 16384
                                        and args.sparse_per_col == 0) else 0
     out = measure(args.rows, args.cols, args.seed, args.sparse_per_col, args.price, args.numerics,
-                  args.steps, args.warmup, late_pivots, deep_pivots, args.whole_solve)
+                  args.steps, args.warmup, late_pivots, deep_pivots, args.whole_solve,
+                  mfma_block=late_pivots > 0 and not args.no_mfma)
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
     out["roofline"]["traffic_detail"] = traffic
     if under_profiler():
