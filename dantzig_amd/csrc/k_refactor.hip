@@ -18,6 +18,8 @@
 //      position of the basic slack of row r' (one more MFMA GEMM), eta file emptied.
 //
 // ~2.7 k^3 + 2 (m-k) k^2 flops, all but the panels in GEMM form.
+#include <cstdlib>
+
 #include "common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -66,6 +68,92 @@ __global__ __launch_bounds__(256) void k_ref_gemm(int M, int N, int K, const dou
             const int col = c0 + 16 * j + li;
             const double b = (tin && col < N) ? bp[col] : 0.0;
             acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            if (row < M && col < N) C[(long long)(crow ? crow[row] : row) * ldc + col] = acc[j][g];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_ref_gemm_lds: the same product with B staged through LDS.  The four waves of a workgroup own
+// four 16 x 64 strips of the SAME 64 columns of C, so they multiply by the same K x 64 panel of B:
+// it is fetched once per workgroup, 64 rows of K at a time (32 KB, coalesced 16-byte loads, one
+// trip), and every MFMA takes its B operand from LDS; only A (one value per lane and 4 MFMAs, four
+// steps per trip) and the C tile itself still come from memory.  In k_ref_gemm every wave loads
+// its own copy of B from L2 -- 5 loads per 4 MFMAs, the L1 at its limit: 25 % of the fp64 MFMA
+// peak on the rank-64 updates of the factorisation.  Occupancy stays at 4 waves per SIMD (128
+// VGPRs, 36 KB of LDS per workgroup): latency is hidden by waves, as there.
+// Same lane maps, same order of the K steps: bit-identical results.
+// ---------------------------------------------------------------------------------
+#define GKC 64  // rows of B per LDS panel
+#define GLD 72  // LDS row stride in doubles (k -> k + 1 moves 16 banks on)
+
+typedef double double2r_t __attribute__((ext_vector_type(2)));
+
+template <bool ZERO_C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ref_gemm_lds(
+    int M, int N, int K, const double *__restrict__ A, long long lda, const double *__restrict__ B,
+    long long ldb, double *__restrict__ C, long long ldc, const int *__restrict__ crow)
+{
+    __shared__ __attribute__((aligned(16))) double s_b[GKC][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * 64;
+    const int i0 = (blockIdx.y * 4 + wave) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            double cv = 0.0;
+            if (!ZERO_C && row < M && col < N) cv = C[(long long)(crow ? crow[row] : row) * ldc + col];
+            acc[j][g] = cv;
+        }
+    }
+    const int arow = i0 + li;
+    const double *ap = A + (long long)(arow < M ? arow : M - 1) * lda;
+    // staging map of B: thread loads 8 x double2: k = (tid >> 5) + 8 u, columns 2 (tid & 31) ..+1
+    const int b_k = tid >> 5, b_c = 2 * (tid & 31);
+    for (int k0 = 0; k0 < K; k0 += GKC) {
+        double2r_t rb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k0 + b_k + 8 * u, c = c0 + b_c;
+            const double *p = B + (long long)(kk < K ? kk : K - 1) * ldb;
+            double2r_t w;
+            w.x = p[c < N ? c : N - 1];
+            w.y = p[c + 1 < N ? c + 1 : N - 1];
+            if (kk >= K || c >= N) w.x = 0.0;
+            if (kk >= K || c + 1 >= N) w.y = 0.0;
+            rb[u] = w;
+        }
+        if (k0 > 0) __syncthreads(); // everybody is done with the previous panel
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<double2r_t *>(&s_b[b_k + 8 * u][b_c]) = rb[u];
+        __syncthreads();
+        for (int s0 = 0; s0 < GKC / 4; s0 += 4) { // A: four steps' values per trip
+            double av[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int t = k0 + 4 * (s0 + s) + lk;
+                av[s] = ap[t < K ? t : K - 1];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool tin = k0 + 4 * (s0 + s) + lk < K;
+                const double a = (arow < M && tin) ? -av[s] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, s_b[4 * (s0 + s) + lk][16 * j + li], acc[j],
+                                                                  0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -551,6 +639,13 @@ static void gemm_sub(int M, int N, int K, const double *A, long long lda, const 
                      long long ldb, double *C, long long ldc, hipStream_t st)
 {
     if (M <= 0 || N <= 0 || K <= 0) return;
+    // large shapes: B through LDS (k_ref_gemm_lds); a grid that does not fill the chip twice over
+    // keeps every wave on its own (no workgroup barrier)
+    if ((long long)((M + 63) / 64) * ((N + 63) / 64) >= 512 && !std::getenv("DZG_REF_GEMM_STRIPS")) {
+        hipLaunchKernelGGL((k_ref_gemm_lds<false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, M,
+                           N, K, A, lda, B, ldb, C, ldc, (const int *)nullptr);
+        return;
+    }
     hipLaunchKernelGGL((k_ref_gemm<false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, M, N,
                        K, A, lda, B, ldb, C, ldc, (const int *)nullptr);
 }
@@ -645,8 +740,12 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
                 hipLaunchKernelGGL(k_ref_gather_slack, dim3((k + 255) / 256, nl), dim3(256), 0, st, k,
                                    d.A, d.lda, d.col0, lrow, scode, G, ldg);
             }
-            hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
-                               nl, k, k, G, ldg, X, ldg, d.binv, d.ldb, (const int *)lpos);
+            if ((long long)((nl + 63) / 64) * ((k + 63) / 64) >= 512 && !std::getenv("DZG_REF_GEMM_STRIPS"))
+                hipLaunchKernelGGL((k_ref_gemm_lds<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
+                                   nl, k, k, G, ldg, X, ldg, d.binv, d.ldb, (const int *)lpos);
+            else
+                hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
+                                   nl, k, k, G, ldg, X, ldg, d.binv, d.ldb, (const int *)lpos);
         }
     }
     hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);
