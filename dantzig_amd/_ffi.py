@@ -60,7 +60,7 @@ class Opts(C.Structure):
         ("world", C.c_int32), ("stream", C.c_void_p), ("refactor_interval", C.c_int64),
         ("a_is_block", C.c_int32), ("near_tie_action", C.c_int32),
         ("replicate_matrix", C.c_int32), ("auto_restart_rows", C.c_int32), ("tie_tol", C.c_double),
-        ("seven_launches", C.c_int32), ("reserved0", C.c_int32),
+        ("seven_launches", C.c_int32), ("auto_strict_budget_s", C.c_int32),
     ]
 
 

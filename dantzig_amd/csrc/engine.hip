@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -105,6 +106,7 @@ struct dzg_solver {
     int64_t refactors = 0;
     double *A_alloc = nullptr;  // device matrix as allocated (d.A points at column col0 inside it)
     long long cols_present = 0; // structural columns uploaded so far (replicate_matrix + a_is_block)
+    std::vector<std::pair<int64_t, int64_t>> col_blocks; // ... as disjoint intervals [begin, end)
     double drift_trigger = 1e-9; // FAST health: disagreement of the two pivot elements that
                                  // triggers a refactorisation
     double max_err_life = 0.0; // largest ctl->max_pivot_err ever read (the device value restarts
@@ -299,8 +301,16 @@ extern "C" int dzg_solver_upload_columns(dzg_solver *s, int64_t col_begin, int64
     if (col_begin < 0 || col_end > s->d.ns || col_begin > col_end || lda < s->d.m ||
         (col_begin < s->d.col1 && col_end > s->d.col0))
         return fail(DZG_E_ARG, "upload_columns: [col_begin, col_end) must lie outside the rank's own block");
+    // every column exactly once: a block handed over twice would leave another one unset (zeros)
+    // behind a column count that looks complete
+    for (const auto &blk : s->col_blocks)
+        if (col_begin < blk.second && col_end > blk.first)
+            return fail(DZG_E_ARG, "upload_columns: columns [" + std::to_string(col_begin) + ", " +
+                                       std::to_string(col_end) + ") overlap a block that is already present");
     HIP_OK(hipSetDevice(s->opts.device));
-    return upload_columns(s, col_begin, col_end, a, lda);
+    TRY(upload_columns(s, col_begin, col_end, a, lda));
+    if (col_end > col_begin) s->col_blocks.emplace_back(col_begin, col_end);
+    return 0;
 }
 
 extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_solver **out)
@@ -456,9 +466,14 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     d.A = A;
     if (d.repl && !o.a_is_block && ns > nloc) {
         // lp->a is the whole matrix: the other ranks' columns come from it right away
-        if (d.col0 > 0) TRY(upload_columns(s, 0, d.col0, lp->a, lp->lda));
-        if (d.col1 < ns)
+        if (d.col0 > 0) {
+            TRY(upload_columns(s, 0, d.col0, lp->a, lp->lda));
+            s->col_blocks.emplace_back(0, d.col0);
+        }
+        if (d.col1 < ns) {
             TRY(upload_columns(s, d.col1, ns, lp->a + (size_t)d.col1 * (size_t)lp->lda, lp->lda));
+            s->col_blocks.emplace_back(d.col1, ns);
+        }
     }
 
     // --- index maps
@@ -888,7 +903,12 @@ static int health_check(dzg_solver *s, bool *stop)
         // accept a larger disagreement instead of refactorising every batch
         const bool fresh = s->refactors > 0 && s->since_refactor <= 2ll * s->opts.poll_interval;
         if (fresh) s->drift_trigger *= 100.0;
-        if ((fresh && s->h_ctl->max_pivot_err > 1e-4) || refactor_now(s) != 0) {
+        int rrc = 0;
+        if (!(fresh && s->h_ctl->max_pivot_err > 1e-4)) rrc = refactor_now(s);
+        // (a refactorisation that FAILED as a call -- device error, out of memory -- is that error,
+        // not a singular basis)
+        if (rrc == DZG_E_DEVICE || rrc == DZG_E_NOMEM) return rrc;
+        if ((fresh && s->h_ctl->max_pivot_err > 1e-4) || rrc != 0) {
             s->h_ctl->max_pivot_err = 1.0;
             TRY(health_stop(s));
             *stop = true;
@@ -1476,7 +1496,38 @@ extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result
         strict.numerics = DZG_NUMERICS_STRICT;
         strict.refactor_interval = 0;
         strict.near_tie_action = DZG_NEAR_TIE_COUNT;
-        rc = solve_once(lp, &strict, res);
+        // The re-solve costs 3-57 ms per pivot: it runs against a wall-clock budget (an
+        // integer model with many thousands of pivots would otherwise sit here for an hour without
+        // a sign of life).  Out of budget: FAST from the first pivot with near ties COUNTED -- the
+        // caller sees numerics_used = FAST and near_ties / first_near_tie, i.e. from which pivot on
+        // the path is no longer certified to be the reference's.
+        const double budget_s = o.auto_strict_budget_s < 0 ? -1.0
+                                : (o.auto_strict_budget_s == 0 ? 600.0 : (double)o.auto_strict_budget_s);
+        dzg_solver *ss = nullptr;
+        rc = dzg_solver_create(lp, &strict, &ss);
+        if (rc != 0) return rc;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool out_of_time = false;
+        for (;;) {
+            rc = dzg_solver_run(ss, 256);
+            if (rc != DZG_ITER_LIMIT || ss->h_ctl->iter >= strict.max_iter) break;
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (budget_s >= 0.0 && el > budget_s) { out_of_time = true; break; }
+        }
+        if (rc < 0) {
+            dzg_solver_destroy(ss);
+            return rc;
+        }
+        if (!out_of_time) {
+            const int rc2 = dzg_solver_result(ss, res);
+            dzg_solver_destroy(ss);
+            return rc2 != 0 ? rc2 : rc;
+        }
+        dzg_solver_destroy(ss);
+        dzg_opts fast = o;
+        fast.numerics = DZG_NUMERICS_FAST;
+        fast.near_tie_action = DZG_NEAR_TIE_COUNT;
+        rc = solve_once(lp, &fast, res);
     }
     return rc;
 }

@@ -156,7 +156,12 @@ typedef struct {
                                  inside, csrc/k_chain.hip; sharded: the same two kernels between the
                                  exchanges); 1 = the seven launches a partitioned rank runs.  Same
                                  arithmetic, same pivots. */
-    int32_t reserved0;
+    int32_t auto_strict_budget_s; /* AUTO: wall-clock seconds the STRICT re-solve may take (31-57 ms per
+                                 pivot at 1024-2048 rows: an LP with tens of thousands of pivots
+                                 would take an hour).  When it runs out the LP is solved in FAST
+                                 numerics with near ties counted, and the result says so
+                                 (near_ties > 0, numerics_used = FAST).  0 = default (600 s),
+                                 < 0 = no limit */
 } dzg_opts;
 
 /* What FAST numerics does at a near tie (the pivot rule is a first-wins strict argmax,

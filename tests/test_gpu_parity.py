@@ -750,6 +750,22 @@ def test_auto_follows_the_oracle_on_integer_lps(core):
     assert strict > 150  # these LPs are full of ties: nearly all must have been handed to STRICT
 
 
+def test_auto_strict_resolve_runs_against_a_wall_clock_budget(core):
+    """AUTO re-solves an LP that met a near tie in STRICT (3-57 ms per pivot): with a budget of one
+    second an integer LP of 333 rows whose solve needs thousands of pivots (seed 9000 of the fixture
+    is still running at its cap of 120) must not sit in STRICT -- it comes back from FAST with the
+    near ties counted (numerics 'fast', near_ties > 0); with the default budget the same call is the
+    STRICT answer."""
+    from tests.lp_families import make_lp
+
+    a, b, c = make_lp(9000, 1, 200, 400)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    quick = core.core_solve(lp, numerics=core.AUTO, max_iter=100000, log_cap=16, auto_strict_budget_s=1)
+    assert quick.numerics == "fast" and quick.near_ties > 0 and quick.first_near_tie >= 0
+    full = core.core_solve(lp, numerics=core.AUTO, max_iter=120, log_cap=120)
+    assert full.numerics == "strict" and full.iterations == 120
+
+
 def test_fast_leaves_the_oracle_path_only_where_it_flagged_a_near_tie(core):
     """FAST with near ties COUNTED (no stop) on 150 small LPs of all three families: wherever its
     pivot log or verdict differs from the oracle's, a near tie was flagged at or before the first

@@ -328,6 +328,11 @@ def test_replicated_sharding_from_column_blocks_and_refactorisation():
                 if other != r:
                     ob, oe = col_range(ns, other, world)
                     s.upload_columns(ob, oe, np.asarray(a)[:, ob:oe])
+        # every column exactly once: handing a block over twice is refused (it would leave another
+        # one unset behind a column count that looks complete)
+        ob, oe = col_range(ns, 1, world)
+        with pytest.raises(_ffi.DantzigAmdError, match="overlap"):
+            solvers[0].upload_columns(ob, oe, np.asarray(a)[:, ob:oe])
         status = run_lockstep(solvers)
         results = [s.result() for s in solvers]
     finally:
