@@ -587,8 +587,8 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             HIP_OK(hipMemsetAsync(d.acol, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
             HIP_OK(hipMemsetAsync(d.dxs, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
         }
-        // one GPU, or a column-sharded rank that keeps the whole matrix (the entering column is local)
-        if ((d.world == 1 || d.repl) && !d.csc && !o.seven_launches) {
+        // dense matrix: one GPU, or a column-sharded rank (replicated or partitioned storage)
+        if (!d.csc && !o.seven_launches) { // (a partitioned rank takes the column from the record)
             // the chain's barriers need every workgroup resident at once: one per CU, and the
             // runtime must agree that a workgroup of either kernel fits a CU at all (registers,
             // 136 KB of LDS); otherwise the barrier-free seven launches run
@@ -1151,7 +1151,7 @@ extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *s
     hipStream_t st = s->st;
     const int pk = price_kernel_for(s);
     phase_stamp(s, DZG_K_FTRAN, 0);
-    if (s->batch_chain) { // (replicated matrix) the three kernels below in one launch, k_chain.hip
+    if (s->batch_chain) { // the three kernels below in one launch, k_chain.hip
         dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, recv_dev, st);
     } else {
         dzg_launch_fast_select_prep(d, 4, 0, recv_dev, st);    // merge + status() + primal FTRAN prep

@@ -172,6 +172,18 @@ __device__ __forceinline__ void chain_stage_ag(double *s_ag, int k, int code,
         s_ag[c] = c < k ? (code < 0 ? (drow[c] == rr ? 1.0 : 0.0) : a[drow[c]]) : 0.0;
 }
 
+// The entering column: the device's own matrix (one GPU, or a sharded rank that keeps every column),
+// or -- a PARTITIONED rank, whose HBM holds its own block only -- the copy that travels in the
+// winner's exchange record (8 header doubles, then the column; include/dantzig_amd.h).
+template <bool SHARD>
+__device__ __forceinline__ const double *chain_col(const DzgDev &d, int code,
+                                                   const double *__restrict__ xrecv, int w_rec)
+{
+    if (code < 0) return nullptr;
+    if (SHARD && d.xstride > 8) return xrecv + (long long)w_rec * d.xstride + 8;
+    return d.A + (long long)(code - d.col0) * d.lda;
+}
+
 // beta_t = W_t . a_j by workgroup t, published for everybody
 __device__ __forceinline__ void chain_beta(const DzgDev &d, int neta, int code,
                                            const double *__restrict__ a)
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
             zr = d.z[epos];
             zbr = d.zbar[epos];
         }
-        const double *a = code < 0 ? nullptr : d.A + (long long)(code - d.col0) * d.lda;
+        const double *a = chain_col<SHARD>(d, code, xrecv, w_rec);
         // this row's unit-column share of dx (fast_gemv_unit's term), loaded beside the gather
         const bool has_unit = has_row && bcode_i < 0;
         double unit_i = 0.0;
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
                 zbr = d.zbar[r];
                 dzr = d.dz[r];
             }
-            const double *a = cj < 0 ? nullptr : d.A + (long long)(cj - d.col0) * d.lda;
+            const double *a = chain_col<SHARD>(d, cj, xrecv, w_rec);
             edslot = cj < 0 ? d.dslot[-1 - cj] : -1;
             const bool has_unit = has_row && bcode_i < 0;
             double unit_i = 0.0, unit_p = 0.0;
