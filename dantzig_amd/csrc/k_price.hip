@@ -22,14 +22,16 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
     // 16 with 12 columns per wave, 12 324 nonbasic structural columns deep in the benchmark solve,
     // streamed at 5.9 TB/s against 6.6 with every slot used, profiles/r03_deep_regime_*).  More
     // than 16 columns: the fewest passes of equal width.  Tiles in flight follow the width so that
-    // a wave keeps 26-36 KB on its way.  The sums do not depend on any of this (only on m).
+    // a wave keeps 26-40 KB on its way, two adjacent tiles per visit of a column where that measured
+    // faster (tools/price_width_bench.hip, profiles/r03_price_width_microbench.txt).  The sums do not
+    // depend on any of this (only on m).
     const int passes = (per_wave + 15) / 16;
     const int cw = passes > 0 ? (per_wave + passes - 1) / passes : 1;
 #define TREE(CW, DEPTH, TP)                                                                          \
     hipLaunchKernelGGL((k_price_tree<CW, DEPTH, TP>), grid, block, 0, st, PRICE_ARGS, pcode)
-    // (15-16 columns per wave in two passes of 8 with 2-KiB visits: 160.8 us against 162.7 at 8192
-    // rows, profiles/r02_price_microbench_adjacent_tiles.txt)
-    if (passes == 2 && cw == 8) { TREE(8, 2, 2); return; }
+    // (15-16 columns per wave: two passes of 8 with 2-KiB visits, 160.8 us against 162.7 for one pass
+    // of 16 at 8192 rows, profiles/r02_price_microbench_adjacent_tiles.txt)
+    if (per_wave == 15 || per_wave == 16) { TREE(8, 2, 2); return; }
     switch (cw) {
     case 16: TREE(16, 2, 1); break;
     case 15: TREE(15, 2, 1); break;
@@ -37,12 +39,12 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
     case 13: TREE(13, 2, 1); break;
     case 12: TREE(12, 3, 1); break;
     case 11: TREE(11, 3, 1); break;
-    case 10: TREE(10, 3, 1); break;
-    case 9: TREE(9, 3, 1); break;
-    case 8: TREE(8, 4, 1); break;
+    case 10: TREE(10, 2, 2); break;
+    case 9: TREE(9, 2, 2); break;
+    case 8: TREE(8, 2, 2); break;
     case 7: TREE(7, 4, 1); break;
-    case 6: TREE(6, 5, 1); break;
-    case 5: TREE(5, 6, 1); break;
+    case 6: TREE(6, 3, 2); break;
+    case 5: TREE(5, 4, 2); break;
     case 4: TREE(4, 8, 1); break;
     case 3: TREE(3, 10, 1); break;
     case 2: TREE(2, 16, 1); break;
