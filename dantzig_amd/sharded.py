@@ -70,6 +70,23 @@ class ShardedSolver(core.Solver):
         _ffi.check(rc, "dzg_shard_run")
         return core.STATUS_NAMES[rc]
 
+    # -- a host that moves the exchange records itself (any collective layer) drives the three
+    # enqueue-only phases of an iteration; send / recv are DEVICE addresses it owns
+    def set_budget(self, max_new_iters: int = 0) -> str:
+        rc = _ffi.lib().dzg_solver_set_budget(self._h, int(max_new_iters))
+        _ffi.check(rc, "dzg_solver_set_budget")
+        return core.STATUS_NAMES.get(rc, str(rc))
+
+    def phase1(self, send_dev: int) -> None:
+        _ffi.check(_ffi.lib().dzg_shard_phase1(self._h, C.c_void_p(send_dev)), "dzg_shard_phase1")
+
+    def phase2(self, recv_dev: int, send_dev: int) -> None:
+        _ffi.check(_ffi.lib().dzg_shard_phase2(self._h, C.c_void_p(recv_dev), C.c_void_p(send_dev)),
+                   "dzg_shard_phase2")
+
+    def phase3(self, recv_dev: int) -> None:
+        _ffi.check(_ffi.lib().dzg_shard_phase3(self._h, C.c_void_p(recv_dev)), "dzg_shard_phase3")
+
     def comm_size(self) -> int:
         rc = _ffi.lib().dzg_shard_comm_size(self._h)
         _ffi.check(rc, "dzg_shard_comm_size")

@@ -343,3 +343,102 @@ def test_replicated_sharding_from_column_blocks_and_refactorisation():
         assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
         assert res.refactors >= 2
         assert abs(res.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+
+
+# ------------------------------------------------------------------ several OS processes, one GPU
+def _hip():
+    """The HIP runtime the library itself uses, for the test's own device buffers."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    return hip
+
+
+def _gpu_phase_worker(rank, world, port, seed, m, ns, out):
+    """One rank = one OS process with its own solver on the one GPU.  The host drives
+    dzg_shard_phase1 / 2 / 3 itself and moves the records with torch.distributed over gloo (device
+    -> host -> all-gather -> device): the product's phase kernels in a real multi-process run."""
+    import ctypes as C
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dantzig_amd import core
+        from dantzig_amd.sharded import ShardedSolver, all_gather_records, col_range
+
+        begin, end = col_range(ns, rank, world)
+        ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)   # this rank's columns only
+        lp = core.CoreLP.from_inequality_block(ab, bb, cb, begin, end)
+        hip = _hip()
+        with ShardedSolver(lp, rank, world, poll_interval=1) as s:
+            nrec = s.record_doubles
+            send, recv = C.c_void_p(), C.c_void_p()
+            assert hip.hipMalloc(C.byref(send), 8 * nrec) == 0
+            assert hip.hipMalloc(C.byref(recv), 8 * nrec * world) == 0
+            h_send = torch.zeros(nrec, dtype=torch.float64)
+            h_recv = torch.zeros(nrec * world, dtype=torch.float64)
+
+            def exchange():
+                assert hip.hipMemcpy(h_send.data_ptr(), send, 8 * nrec, 2) == 0      # device -> host
+                all_gather_records(h_send, h_recv)
+                assert hip.hipMemcpy(recv, h_recv.data_ptr(), 8 * nrec * world, 1) == 0  # host -> device
+
+            assert s.set_budget(0) == "running"
+            status, pivots = "running", 0
+            while status == "running" and pivots < 20000:
+                s.phase1(send.value)
+                exchange()
+                s.phase2(recv.value, send.value)
+                exchange()
+                s.phase3(recv.value)
+                status, pivots = s.poll()
+            res = s.result()
+            hip.hipFree(send)
+            hip.hipFree(recv)
+        out.put((rank, status, res.pivots, res.x.tolist(), res.objective))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,seed,m,ns", [(2, 45, 96, 200), (3, 46, 64, 150)])
+def test_sharded_processes_on_one_gpu_exchange_over_gloo(world, seed, m, ns):
+    """The column-sharded device path as SEVERAL OS PROCESSES (one rank each, all on this one GPU),
+    the host driving dzg_shard_phase1 / 2 / 3 and exchanging the records with torch.distributed
+    (gloo): every rank holds only its own column block (partitioned storage, a_is_block), the
+    entering column travels in the records.  Every rank must take the oracle's pivots and hold the
+    single-GPU FAST solve's numbers bit for bit.  (RCCL refuses two ranks on one device; the RCCL loop
+    itself runs with one rank in test_rccl_single_rank_loop.)"""
+    import torch.multiprocessing as mp
+
+    from dantzig_amd import core
+
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    single = core.solve(core.CoreLP.from_inequality_form(a, b, c), numerics=core.FAST, poll_interval=1,
+                        seven_launches=1)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_phase_worker, args=(r, world, port, seed, m, ns, out))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert want.status == single.status == "optimal"
+    for _, status, pivots, x, objective in results:
+        assert status == "optimal"
+        assert [(k, e, l) for k, e, l, _ in pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+        assert [tuple(p) for p in pivots] == [tuple(p) for p in single.pivots]   # mu too, exactly
+        assert x == single.x.tolist() and objective == single.objective
