@@ -670,8 +670,10 @@ __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double
                                                        long long ldu, const double *__restrict__ W,
                                                        long long ldw)
 {
+    // (a flush folds a FULL eta file, like k_fast_flush_mfma: one enqueued behind an iteration that
+    // did not pivot is a no-op)
     const int neta = ctl->neta, k = ctl->ncompact;
-    if (neta <= 0 || k <= 0 || ctl->status != DZG_RUNNING) return;
+    if (neta < R_ || k <= 0 || ctl->status != DZG_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64;
     const int i0 = (blockIdx.y * 4 + wave) * 16;
@@ -686,14 +688,27 @@ __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double
             acc[j][g] = (row < k && col < k) ? X[(long long)row * ldb + col] : 0.0;
         }
     const int arow = i0 + li;
-    const int ksteps = (neta + 3) >> 2;
-    for (int s = 0; s < ksteps; ++s) {
+    // all 80 operands of the tile's 64 MFMAs in one trip (the eta file is full: 16 steps), as in
+    // k_fast_flush_mfma: fetched step by step the flush ran at 1.8 TB/s -- and at k = 39 000 it is
+    // 24 GB every 64 pivots, most of a config-4 pivot deep in the solve
+    const int arowc = arow < k ? arow : 0;
+    double av[R_ / 4], bv[R_ / 4][4];
+#pragma unroll
+    for (int s = 0; s < R_ / 4; ++s) {
         const int t = 4 * s + lk;
-        const double a = (arow < k && t < neta) ? -U[(long long)t * ldu + arow] : 0.0;
+        av[s] = U[(long long)t * ldu + arowc];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = c0 + 16 * j + li;
-            const double b = (t < neta && col < k) ? W[(long long)t * ldw + col] : 0.0;
+            bv[s][j] = W[(long long)t * ldw + (col < k ? col : 0)];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < R_ / 4; ++s) {
+        const double a = arow < k ? -av[s] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double b = c0 + 16 * j + li < k ? bv[s][j] : 0.0;
             acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
         }
     }
@@ -708,7 +723,7 @@ __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double
 
 __global__ void k_sp_flush_done(DzgCtl *ctl)
 {
-    if (ctl->status == DZG_RUNNING) ctl->neta = 0;
+    if (ctl->status == DZG_RUNNING && ctl->neta >= R_) ctl->neta = 0;
 }
 
 // ---------------------------------------------------------------------------------
