@@ -9,7 +9,7 @@ every pivot: an interrupted run keeps what it has.  Each record is what
 src/simplex.rs:274-306,308-330 decides -- (kind, entering, leaving) -- with mu* of that
 iteration and the seconds of CPU the pivot took on one core of the machine that ran this.
 
-  python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots [--blocked]
+  python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots [--blocked] [--resume]
   (BASELINE config 3: 1003 8192 16384 8  -- about 6.5 minutes per pivot)
 
 --blocked: the twin library (oracle/dzg_oracle_blocked.c: Matrix::factorize applied block by
@@ -17,6 +17,10 @@ block on several cores, the same operations per element in the same order -- bit
 tests/test_oracle_kats.py), some 20 s per pivot at 8192 rows; the file is then called
 oracle_blocked_pivots_<seed>_<m>x<ns>.json and says so.  The literal run's pivots are the check
 on it: both files exist for config 3 and tests/test_oracle_kats.py compares them.
+
+--resume: continue from the checkpoint the last run left (the oracle's six state arrays after its
+last pivot, gpurun_out/oracle_ckpt_<seed>_<m>x<ns>.npz -- scratch, not committed) instead of from
+the first pivot.  A fixture on disk is only ever replaced by a LONGER one.
 """
 import ctypes as C
 import json
@@ -47,12 +51,30 @@ if __name__ == "__main__":
     col_ptr, row_idx, val, cc = ora._i64(sf.col_ptr), ora._i64(sf.row_idx), ora._f64(sf.val), ora._f64(sf.c)
     st = ora._Simplex(m, n, ora._p(col_ptr), ora._p(row_idx), ora._p(val), ora._p(cc), float(sf.constant),
                       ora._p(basis), ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
+    ckpt = os.path.join(ROOT, "gpurun_out", f"oracle_ckpt_{'blocked' if blocked else 'first'}_{seed}_{m}x{ns}.npz")
+    prior = None
+    if "--resume" in sys.argv and os.path.exists(ckpt) and os.path.exists(path):
+        ck = np.load(ckpt)
+        with open(path) as f:
+            prior = json.load(f)
+        if int(ck["pivots"]) == len(prior["kind"]):
+            basis[:], nonbasis[:], x[:], xbar[:], z[:], zbar[:] = (ck[k] for k in ("basis", "nonbasis", "x", "xbar", "z", "zbar"))
+            print(f"resuming after pivot {len(prior['kind'])}", flush=True)
+        else:
+            prior = None
+    existing = 0
+    if os.path.exists(path):
+        with open(path) as f:
+            existing = len(json.load(f)["kind"])
     out = {"seed": seed, "m": m, "n_struct": ns, "generator": "G1 (dantzig_amd.core.gen_dense_lp)",
            "source": ("oracle/dzg_oracle.c + dzg_oracle_blocked.c (libdzg_oracle_blocked.so)" if blocked
                       else "oracle/dzg_oracle.c") + ", one ora_simplex_solve(max_iter=1) call per pivot",
            "kind": [], "entering": [], "leaving": [], "mu": [], "seconds_per_pivot": []}
+    if prior is not None:
+        for key in ("kind", "entering", "leaving", "mu", "seconds_per_pivot"):
+            out[key] = list(prior[key])
     log = (ora._Pivot * 1)()
-    for k in range(pivots):
+    for k in range(len(out["kind"]), pivots):
         iters = C.c_int64(0)
         t0 = time.perf_counter()
         status = the_lib.ora_simplex_solve(C.byref(st), C.c_int64(1), C.byref(iters), log, C.c_int64(1))
@@ -65,8 +87,13 @@ if __name__ == "__main__":
         out["leaving"].append(int(log[0].leaving))
         out["mu"].append(float(log[0].mu))
         out["seconds_per_pivot"].append(round(dt, 1))
-        with open(path + ".tmp", "w") as f:
-            json.dump(out, f)
-        os.replace(path + ".tmp", path)
+        if len(out["kind"]) > existing:  # (a fixture is only ever replaced by a longer one)
+            with open(path + ".tmp", "w") as f:
+                json.dump(out, f)
+            os.replace(path + ".tmp", path)
+            os.makedirs(os.path.dirname(ckpt), exist_ok=True)
+            np.savez(ckpt + ".tmp.npz", pivots=len(out["kind"]), basis=basis, nonbasis=nonbasis, x=x, xbar=xbar,
+                     z=z, zbar=zbar)
+            os.replace(ckpt + ".tmp.npz", ckpt)
         print(f"pivot {k + 1}: {(log[0].kind, log[0].entering, log[0].leaving)} mu {log[0].mu!r} "
               f"in {dt:.1f} s", flush=True)
