@@ -369,15 +369,30 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
                                                            int *__restrict__ piv,
                                                            int *__restrict__ singular)
 {
-    __shared__ double s_rowc[W], s_rowp[W];
-    __shared__ int s_p;
-    const int tid = threadIdx.x;
+    // two workgroup barriers per elimination step (four at first: the block-wide max-loc brought
+    // two of its own and the row exchange one more to protect its buffers): every LDS array is
+    // double-buffered by the parity of the step, so nothing written in step jj + 1 can be something
+    // a thread still reads in step jj - 1
+    __shared__ double s_rowc[2][W], s_rowp[2][W];
+    __shared__ double s_cr[2][16];
+    __shared__ int s_ck[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double a[SPR][W];
+    // (a thread's row segment is W contiguous doubles, 16-byte aligned: 16-byte loads -- the rows of
+    // one load instruction are 64 different cache lines, and the one CU this kernel runs on spends
+    // 64 cycles of address processing per instruction whatever its width)
+    typedef double dbl2_t __attribute__((ext_vector_type(2)));
+    static_assert(W % 2 == 0, "sub-panel width");
 #pragma unroll
     for (int r = 0; r < SPR; ++r) {
         const int i = c0 + tid + 1024 * r;
+        const dbl2_t *src = reinterpret_cast<const dbl2_t *>(G + (long long)(i < k ? i : c0) * ldg + c0);
 #pragma unroll
-        for (int c = 0; c < W; ++c) a[r][c] = (i < k && c < w) ? G[(long long)i * ldg + c0 + c] : 0.0;
+        for (int c = 0; c < W; c += 2) {
+            const dbl2_t v2 = src[c / 2];
+            a[r][c] = (i < k && c < w) ? v2.x : 0.0;
+            a[r][c + 1] = (i < k && c + 1 < w) ? v2.y : 0.0;
+        }
     }
 #pragma unroll
     for (int jj = 0; jj < W; ++jj) {
@@ -396,73 +411,136 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
                 if (c.r == c.r) best = dzg_better(best, c);
             }
         }
-        best = dzg_block_best(best);
+        const int buf = jj & 1;
+        best = dzg_wave_best(best);
+        if (lane == 0) {
+            s_cr[buf][wave] = best.r;
+            s_ck[buf][wave] = best.k;
+        }
+        __syncthreads();
+        {
+            DzgCand o;
+            o.r = lane < 16 ? s_cr[buf][lane] : 0.0;
+            o.k = lane < 16 ? s_ck[buf][lane] : -1;
+            best = dzg_wave_best(o); // (the same fan-in as dzg_block_best: 16 wave winners)
+        }
         const int p = best.k >= 0 ? best.k : col;
         if (tid == 0) {
             piv[col] = p;
             if (!(best.r > 0.0)) *singular = 1;
         }
         // the two rows trade places through LDS (row col lives in thread jj's slot 0)
-        __syncthreads();
 #pragma unroll
         for (int r = 0; r < SPR; ++r) {
             const int i = c0 + tid + 1024 * r;
             if (i == col)
 #pragma unroll
-                for (int c = 0; c < W; ++c) s_rowc[c] = a[r][c];
+                for (int c = 0; c < W; ++c) s_rowc[buf][c] = a[r][c];
             if (i == p)
 #pragma unroll
-                for (int c = 0; c < W; ++c) s_rowp[c] = a[r][c];
+                for (int c = 0; c < W; ++c) s_rowp[buf][c] = a[r][c];
         }
         __syncthreads();
-        const double pv = s_rowp[jj];
+        const double pv = s_rowp[buf][jj];
         const double rpv = pv != 0.0 ? 1.0 / pv : 0.0;
 #pragma unroll
         for (int r = 0; r < SPR; ++r) {
             const int i = c0 + tid + 1024 * r;
             if (i == col) {
 #pragma unroll
-                for (int c = 0; c < W; ++c) a[r][c] = s_rowp[c];
+                for (int c = 0; c < W; ++c) a[r][c] = s_rowp[buf][c];
             } else if (i == p) { // p != col here
 #pragma unroll
-                for (int c = 0; c < W; ++c) a[r][c] = s_rowc[c];
+                for (int c = 0; c < W; ++c) a[r][c] = s_rowc[buf][c];
             }
             if (i > col && i < k) {
                 const double l = a[r][jj] * rpv;
                 a[r][jj] = l;
 #pragma unroll
                 for (int c = 0; c < W; ++c)
-                    if (c > jj) a[r][c] = fma(-l, s_rowp[c], a[r][c]);
+                    if (c > jj) a[r][c] = fma(-l, s_rowp[buf][c], a[r][c]);
             }
         }
-        (void)s_p;
     }
 #pragma unroll
     for (int r = 0; r < SPR; ++r) {
         const int i = c0 + tid + 1024 * r;
-        if (i < k)
+        if (i < k) {
+            dbl2_t *dst = reinterpret_cast<dbl2_t *>(G + (long long)i * ldg + c0);
 #pragma unroll
-            for (int c = 0; c < W; ++c)
-                if (c < w) G[(long long)i * ldg + c0 + c] = a[r][c];
+            for (int c = 0; c < W; c += 2) {
+                if (c + 1 < w) {
+                    dbl2_t v2;
+                    v2.x = a[r][c];
+                    v2.y = a[r][c + 1];
+                    dst[c / 2] = v2;
+                } else if (c < w) {
+                    G[(long long)i * ldg + c0 + c] = a[r][c];
+                }
+            }
+        }
     }
     __syncthreads();
-    // the other columns of the enclosing panel: row swaps, then U12' = L11^-1 A12' (as above)
+    // the other columns of the enclosing panel: row swaps, then U12' = L11^-1 A12' (as above).
+    // The w swaps are applied to REGISTER copies of the (at most 2 w) rows they touch -- rows
+    // c0 .. c0 + w - 1 and the pivot rows -- fetched together: taken one swap after the other
+    // through memory (two dependent loads and two stores each) this tail was most of the kernel.
     const int nother = pnbw - w;
     if (tid < nother) {
         const int off = tid < (c0 - pj0) ? tid : tid + w;
         double *colp = G + pj0 + off;
-        for (int jj = 0; jj < w; ++jj) {
-            const int r = c0 + jj, p = piv[r];
-            if (p != r) {
-                const double x0 = colp[(long long)r * ldg], x1 = colp[(long long)p * ldg];
-                colp[(long long)r * ldg] = x1;
-                colp[(long long)p * ldg] = x0;
+        int pr[W];
+        double top[W], piv_v[W]; // values at rows c0 + jj and at rows p_jj (before any swap)
+#pragma unroll
+        for (int jj = 0; jj < W; ++jj) pr[jj] = jj < w ? piv[c0 + jj] : c0 + jj;
+#pragma unroll
+        for (int jj = 0; jj < W; ++jj) {
+            top[jj] = jj < w ? colp[(long long)(c0 + jj) * ldg] : 0.0;
+            piv_v[jj] = jj < w ? colp[(long long)pr[jj] * ldg] : 0.0;
+        }
+        // replay the swaps on the copies: a row's current value lives in top[] if it is one of the
+        // first w rows, else in the piv_v[] slot of the FIRST step that names it
+#pragma unroll
+        for (int jj = 0; jj < W; ++jj) {
+            if (jj >= w) break;
+            const int p = pr[jj];
+            if (p == c0 + jj) continue;
+            if (p < c0 + w) { // both among the first w rows
+                const double x0 = top[jj];
+#pragma unroll
+                for (int t = 0; t < W; ++t)
+                    if (t == p - c0) {
+                        top[jj] = top[t];
+                        top[t] = x0;
+                    }
+            } else {
+                int slot = jj; // the first step whose pivot row is p holds row p's current value
+#pragma unroll
+                for (int t = W - 1; t >= 0; --t)
+                    if (t < jj && pr[t] == p) slot = t;
+                const double x0 = top[jj];
+#pragma unroll
+                for (int t = 0; t < W; ++t)
+                    if (t == slot) {
+                        top[jj] = piv_v[t];
+                        piv_v[t] = x0;
+                    }
             }
+        }
+        // rows below the first w that a swap touched: the slot of the first step naming them
+#pragma unroll
+        for (int jj = 0; jj < W; ++jj) {
+            if (jj >= w || pr[jj] < c0 + w) continue;
+            bool first = true;
+#pragma unroll
+            for (int t = 0; t < W; ++t)
+                if (t < jj && pr[t] == pr[jj]) first = false;
+            if (first) colp[(long long)pr[jj] * ldg] = piv_v[jj];
         }
         if (pj0 + off >= c0 + w) {
             double y[W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) y[i] = i < w ? colp[(long long)(c0 + i) * ldg] : 0.0;
+            for (int i = 0; i < W; ++i) y[i] = i < w ? top[i] : 0.0;
 #pragma unroll
             for (int i = 1; i < W; ++i) {
                 double acc = y[i];
@@ -474,6 +552,10 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
 #pragma unroll
             for (int i = 0; i < W; ++i)
                 if (i < w) colp[(long long)(c0 + i) * ldg] = y[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < W; ++i)
+                if (i < w) colp[(long long)(c0 + i) * ldg] = top[i];
         }
     }
 }
@@ -482,20 +564,40 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
 __global__ __launch_bounds__(256) void k_ref_subupdate(int k, int pj0, int pnbw, int c0, int w,
                                                        double *__restrict__ G, long long ldg)
 {
+    // 32 lanes along a row (two columns each, 16-byte accesses), 8 rows per workgroup and pass: a
+    // wave touches 2 x 448 contiguous bytes per instruction.  (One thread per row walking its row
+    // column by column -- the first version -- made every instruction 64 separate cache lines.)
+    typedef double dbl2_t __attribute__((ext_vector_type(2)));
     __shared__ double s_u[SPW][NB];
     const int right0 = c0 + w, nright = pj0 + pnbw - right0;
     for (int e = threadIdx.x; e < w * nright; e += blockDim.x)
         s_u[e / nright][e % nright] = G[(long long)(c0 + e / nright) * ldg + right0 + e % nright];
     __syncthreads();
-    const int i = right0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k) return;
+    const int cl = 2 * (threadIdx.x & 31), rsub = threadIdx.x >> 5;
+    const int i = right0 + blockIdx.x * 8 + rsub;
+    if (i >= k || cl >= nright) return;
     double *row = G + (long long)i * ldg;
     double l[SPW];
-    for (int j = 0; j < w; ++j) l[j] = row[c0 + j];
-    for (int c = 0; c < nright; ++c) {
-        double acc = row[right0 + c];
-        for (int j = 0; j < w; ++j) acc = fma(-l[j], s_u[j][c], acc);
-        row[right0 + c] = acc;
+#pragma unroll
+    for (int j = 0; j < SPW; ++j) l[j] = j < w ? row[c0 + j] : 0.0;
+    // right0 is even (sub-panels are 8 or 4 columns wide but for the last of a panel): 16-byte aligned
+    if (cl + 1 < nright && ((right0 & 1) == 0)) {
+        dbl2_t acc = *reinterpret_cast<dbl2_t *>(row + right0 + cl);
+#pragma unroll
+        for (int j = 0; j < SPW; ++j)
+            if (j < w) {
+                acc.x = fma(-l[j], s_u[j][cl], acc.x);
+                acc.y = fma(-l[j], s_u[j][cl + 1], acc.y);
+            }
+        *reinterpret_cast<dbl2_t *>(row + right0 + cl) = acc;
+    } else {
+        for (int c = cl; c < nright && c < cl + 2; ++c) {
+            double acc = row[right0 + c];
+#pragma unroll
+            for (int j = 0; j < SPW; ++j)
+                if (j < w) acc = fma(-l[j], s_u[j][c], acc);
+            row[right0 + c] = acc;
+        }
     }
 }
 
@@ -685,7 +787,7 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
                                        G, ldg, piv, singular);
                 const int below = k - c0 - w;
                 if (below > 0 && c0 + w < j0 + nbw)
-                    hipLaunchKernelGGL(k_ref_subupdate, dim3((below + 255) / 256), dim3(256), 0, st,
+                    hipLaunchKernelGGL(k_ref_subupdate, dim3((below + 7) / 8), dim3(256), 0, st,
                                        k, j0, nbw, c0, w, G, ldg);
                 c0 += w;
             }
