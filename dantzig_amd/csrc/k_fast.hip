@@ -29,6 +29,8 @@
 // the heads of these kernels: each workgroup reduces the small arrays of per-workgroup
 // partial candidates left by the previous kernel (deterministic max-loc, lowest position on
 // ties), workgroup 0 publishes the decision in the control block for the next kernel.
+#include <cstdlib>
+
 #include "common.h"
 #include "fast_decide.h"
 #include "fast_rows.h"
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(256) void k_fast_gather_w(const DzgCtl *ctl, const 
 // eta index in steps of 4: D = C - A*B with v_mfma_f64_16x16x4_f64.  Operand lane maps
 // (cdna_hip_programming.md section 3): A[i = l&15][kk = l>>4], B[kk = l>>4][j = l&15],
 // C/D[row = (l>>4) + 4*reg][col = l&15].
+template <bool PRELOAD>
 __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int m,
                                                          double *__restrict__ binv, long long ldb,
                                                          const double *__restrict__ U, long long ldu,
@@ -456,24 +459,36 @@ __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int 
     const int arowc = arow < m ? arow : 0;
     // The eta file is full (neta == R_ = 64): 16 steps of 4 etas, trip count known.  All operands
     // of the 64 MFMAs -- 16 values of U and 64 of Wc per lane -- are fetched BEFORE the first MFMA,
-    // in one trip to L2 / HBM beside the tile of Binv0 itself; fetched step by step (one dependent
-    // trip per step, as this loop first was) a wave spent 16 latencies per tile and the flush ran
-    // at 1.1 TB/s (475 us at k = 4 060).
-    double av[R_ / 4], bv[R_ / 4][4];
+    // in one trip to L2 / HBM beside the tile of Binv0 itself: 161 us per flush at k = 4 060 against
+    // 170 us fetched step by step (DZG_FLUSH_STEPS=1 selects that form for comparison).
+    if (PRELOAD) {
+        double av[R_ / 4], bv[R_ / 4][4];
 #pragma unroll
-    for (int s = 0; s < R_ / 4; ++s) {
-        const int t = 4 * s + lk;
-        av[s] = U[(long long)t * ldu + arowc];
-        const double *wrow = Wc + (long long)t * ldw + c0 + li;
+        for (int s = 0; s < R_ / 4; ++s) {
+            const int t = 4 * s + lk;
+            av[s] = U[(long long)t * ldu + arowc];
+            const double *wrow = Wc + (long long)t * ldw + c0 + li;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[s][j] = wrow[16 * j];
-    }
+            for (int j = 0; j < 4; ++j) bv[s][j] = wrow[16 * j];
+        }
 #pragma unroll
-    for (int s = 0; s < R_ / 4; ++s) {
-        const double a = arow < m ? -av[s] : 0.0;
+        for (int s = 0; s < R_ / 4; ++s) {
+            const double a = arow < m ? -av[s] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s][j], acc[j], 0, 0, 0);
+        }
+    } else {
+        for (int s = 0; s < R_ / 4; ++s) {
+            const int t = 4 * s + lk;
+            const double a = arow < m ? -U[(long long)t * ldu + arowc] : 0.0;
+            const double *wrow = Wc + (long long)t * ldw + c0 + li;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double b = wrow[16 * j];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -685,8 +700,13 @@ void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
     const int kmax = d.m; // ncompact <= m; grids cover the worst case, kernels mask by ctl
     hipLaunchKernelGGL(k_fast_gather_w, dim3((kmax + 15 + 255) / 256, R_), dim3(256), 0, st, d.ctl,
                        d.W, d.ldw, d.drow, d.Wc);
-    hipLaunchKernelGGL(k_fast_flush_mfma, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
-                       d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
+    static const bool steps = std::getenv("DZG_FLUSH_STEPS") != nullptr; // (A/B switch, tools)
+    if (steps)
+        hipLaunchKernelGGL(k_fast_flush_mfma<false>, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
+                           d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
+    else
+        hipLaunchKernelGGL(k_fast_flush_mfma<true>, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
+                           d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
     hipLaunchKernelGGL(k_fast_flush_done, dim3(1), dim3(1), 0, st, d.ctl);
 }
 

@@ -688,27 +688,16 @@ __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double
             acc[j][g] = (row < k && col < k) ? X[(long long)row * ldb + col] : 0.0;
         }
     const int arow = i0 + li;
-    // all 80 operands of the tile's 64 MFMAs in one trip (the eta file is full: 16 steps), as in
-    // k_fast_flush_mfma: fetched step by step the flush ran at 1.8 TB/s -- and at k = 39 000 it is
-    // 24 GB every 64 pivots, most of a config-4 pivot deep in the solve
-    const int arowc = arow < k ? arow : 0;
-    double av[R_ / 4], bv[R_ / 4][4];
-#pragma unroll
-    for (int s = 0; s < R_ / 4; ++s) {
+    // (step by step: fetching all 80 operands of the tile up front, as k_fast_flush_mfma does, measured
+    // 366 us against 131 us per flush at k = 1 175 here -- the masks on W cost registers and waves)
+    const int ksteps = (neta + 3) >> 2;
+    for (int s = 0; s < ksteps; ++s) {
         const int t = 4 * s + lk;
-        av[s] = U[(long long)t * ldu + arowc];
+        const double a = (arow < k && t < neta) ? -U[(long long)t * ldu + arow] : 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = c0 + 16 * j + li;
-            bv[s][j] = W[(long long)t * ldw + (col < k ? col : 0)];
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < R_ / 4; ++s) {
-        const double a = arow < k ? -av[s] : 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double b = c0 + 16 * j + li < k ? bv[s][j] : 0.0;
+            const double b = (t < neta && col < k) ? W[(long long)t * ldw + col] : 0.0;
             acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
         }
     }
