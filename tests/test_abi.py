@@ -91,6 +91,37 @@ def test_rust_mirror_in_integration_md_matches_the_header():
     assert re.findall(r"(\w+):", rust) == c_args
 
 
+def test_full_csc_entry_validates_its_arguments_on_the_host():
+    """dzg_core_solve_full_csc (Level 1 on the reference's own Simplex fields) checks the CSC before
+    anything reaches a device: malformed input is DZG_E_ARG with a reason on any machine; well-formed
+    input without a GPU is DZG_E_DEVICE (there is no CPU path)."""
+    import ctypes as C
+
+    lib = _ffi.lib()
+    i64, f64 = _ffi.i64, _ffi.f64
+    # 2 rows, 3 columns: one structural column + the two slacks, as Simplex::new would leave them
+    col_ptr, row_idx, val = i64([0, 2, 3, 4]), i64([0, 1, 0, 1]), f64([2.0, 1.0, 1.0, 1.0])
+    c, basis, nonbasis = f64([1.0, 0.0, 0.0]), i64([1, 2]), i64([0])
+    x, z = f64([4.0, 3.0]), f64([-1.0])
+    res = _ffi.Result()
+
+    def call(cp=col_ptr, ri=row_idx, m=2, n=3):
+        bb, nn, xx, zz = basis.copy(), nonbasis.copy(), x.copy(), z.copy()   # (in/out arguments)
+        return lib.dzg_core_solve_full_csc(m, n, _ffi.ptr(cp), _ffi.ptr(ri), _ffi.ptr(val), _ffi.ptr(c), 0.0,
+                                           _ffi.ptr(bb), _ffi.ptr(nn), _ffi.ptr(xx), _ffi.ptr(zz), None,
+                                           C.byref(res))
+
+    assert call(cp=i64([0, 2, 1, 4])) == _ffi.E_ARG and b"monotone" in lib.dzg_last_error()
+    assert call(ri=i64([1, 0, 0, 1])) == _ffi.E_ARG and b"ascend" in lib.dzg_last_error()
+    assert call(ri=i64([0, 2, 0, 1])) == _ffi.E_ARG                      # row index out of range
+    assert call(m=4, n=3) == _ffi.E_ARG                                     # n < m
+    assert lib.dzg_core_solve_full_csc(2, 3, _ffi.ptr(col_ptr), _ffi.ptr(row_idx), _ffi.ptr(val), _ffi.ptr(c),
+                                       0.0, _ffi.ptr(basis), _ffi.ptr(nonbasis), _ffi.ptr(x), _ffi.ptr(z),
+                                       None, None) == _ffi.E_ARG            # res is NULL
+    if lib.dzg_device_count() == 0:
+        assert call() == _ffi.E_DEVICE and b"no CPU path" in lib.dzg_last_error()
+
+
 def test_generators_are_deterministic_host_code():
     a1, b1, c1 = core.gen_dense_lp(seed=5, m=7, n_struct=11)
     a2, b2, c2 = core.gen_dense_lp(seed=5, m=7, n_struct=11)
