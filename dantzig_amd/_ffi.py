@@ -48,6 +48,7 @@ class Lp(C.Structure):
         ("c", C.c_void_p), ("constant", C.c_double),
         ("basis", C.c_void_p), ("nonbasis", C.c_void_p), ("x", C.c_void_p), ("z", C.c_void_p),
         ("col_ptr", C.c_void_p), ("row_idx", C.c_void_p), ("val", C.c_void_p),
+        ("xbar", C.c_void_p), ("zbar", C.c_void_p),
     ]
 
 

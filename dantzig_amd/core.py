@@ -39,6 +39,10 @@ class CoreLP:
     # n_struct_full structural columns (opts.a_is_block); everything else is complete
     block: tuple | None = None
     n_struct_full: int | None = None
+    # perturbation vectors (Simplex.x_bar / z_bar); None = ones (Simplex::new).  With a non-slack
+    # basis, its x and z: resume a solve from a CoreResult (CoreLP.resumed_from)
+    xbar: np.ndarray | None = None
+    zbar: np.ndarray | None = None
 
     @property
     def m(self) -> int:
@@ -88,6 +92,18 @@ class CoreLP:
                    nonbasis=np.arange(ns, dtype=np.int64), x=f64(b).copy(), z=-f64(c),
                    constant=constant, col_ptr=i64(col_ptr),
                    row_idx=np.ascontiguousarray(row_idx, dtype=np.int32), val=f64(val))
+
+
+def resumed_from(lp: CoreLP, r) -> CoreLP:
+    """The same LP in the state a CoreResult (or anything with basis, nonbasis, x, xbar, z, zbar)
+    left it in: a solver created on it factorises that basis and carries the solve on."""
+    import dataclasses
+
+    def get(name):  # a CoreResult, or a mapping such as an .npz archive of one
+        return r[name] if hasattr(r, "keys") else getattr(r, name)
+    return dataclasses.replace(lp, basis=i64(get("basis")).copy(), nonbasis=i64(get("nonbasis")).copy(),
+                               x=f64(get("x")).copy(), z=f64(get("z")).copy(),
+                               xbar=f64(get("xbar")).copy(), zbar=f64(get("zbar")).copy())
 
 
 @dataclass
@@ -142,15 +158,19 @@ class Solver:
                           col_ptr=None if lp.col_ptr is None else i64(lp.col_ptr),
                           row_idx=None if lp.row_idx is None
                           else np.ascontiguousarray(lp.row_idx, dtype=np.int32),
-                          val=None if lp.val is None else f64(lp.val))
+                          val=None if lp.val is None else f64(lp.val),
+                          xbar=None if lp.xbar is None else f64(lp.xbar),
+                          zbar=None if lp.zbar is None else f64(lp.zbar))
         k = self._keep
         if len(k["basis"]) != m or len(k["x"]) != m or len(k["nonbasis"]) != n - m \
-                or len(k["z"]) != n - m:
+                or len(k["z"]) != n - m \
+                or (k["xbar"] is not None and len(k["xbar"]) != m) \
+                or (k["zbar"] is not None and len(k["zbar"]) != n - m):
             raise ValueError("CoreLP vectors do not match (m, n)")
         self._c_lp = _ffi.Lp(m, n, ns, ptr(a_cm), max(m, 1), ptr(k["var_col"]), ptr(k["c"]),
                              float(lp.constant), ptr(k["basis"]), ptr(k["nonbasis"]),
                              ptr(k["x"]), ptr(k["z"]), ptr(k["col_ptr"]), ptr(k["row_idx"]),
-                             ptr(k["val"]))
+                             ptr(k["val"]), ptr(k["xbar"]), ptr(k["zbar"]))
         if lp.block is not None:
             if (opts.get("col_begin"), opts.get("col_end")) != tuple(lp.block):
                 raise ValueError("a column-block LP needs a sharded solver on exactly that block")

@@ -13,11 +13,12 @@
 //        ->  row swaps outside the panel  ->  U12 = L11^-1 A12  ->
 //        trailing update A22 -= L21 * U12 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
 //   3. X = G^-1 by blocked forward / backward substitution on the identity, every off-diagonal
-//      block product again an MFMA GEMM
+//      block product again an MFMA GEMM.  The forward half keeps X unit lower triangular (columns in
+//      pivot order, put back by one permutation at the end): k^3 / 3 flops instead of k^3
 //   4. Binv0[p_b, :] = X[b, :] for structural positions, Binv0[p', :] = -A[r', S] * X for the
 //      position of the basic slack of row r' (one more MFMA GEMM), eta file emptied.
 //
-// ~2.7 k^3 + 2 (m-k) k^2 flops, all but the panels in GEMM form.
+// 2 k^3 + 2 (m-k) k^2 flops, all but the panels in GEMM form.
 #include <cstdlib>
 
 #include "common.h"
@@ -282,15 +283,24 @@ __global__ __launch_bounds__(256) void k_ref_lslot_fill(int nl, const int *__res
 //     columns right of the sub-panel (a w x w unit-lower triangle: one thread per column);
 //   k_ref_subupdate (whole chip): A22' -= L21 U12' on rows below the sub-panel, panel columns
 //     right of it -- one thread per row, U12' in LDS.
+//
+// The panel is factorised in a COMPACT COLUMN-MAJOR copy Pn (element (row i, panel column cc) at
+// Pn[cc * ldp + i]; k_ref_panel_in / _out transpose it out of and back into G with the whole
+// chip).  The sub-panel kernels run on ONE compute unit: in G a row's sub-panel segment is 32-64
+// bytes of its own 128-byte line, 4 096-8 192 lines in and as many out through one CU's 64 bytes
+// per clock -- some 25 of the 34-38 us a launch took, whatever the elimination steps cost.  In Pn
+// consecutive threads hold consecutive rows of a column: every access is a full line.
 #define SPW 8
+#define PN(i, cc) Pn[(long long)(cc) * ldp + (i)]
 __global__ __launch_bounds__(1024) void k_ref_subpanel(int k, int pj0, int pnbw, int c0, int w,
-                                                       double *__restrict__ G, long long ldg,
+                                                       double *__restrict__ Pn, long long ldp,
                                                        int *__restrict__ piv,
                                                        int *__restrict__ singular)
 {
     __shared__ int s_p;
     __shared__ double s_pivrow[SPW];
     const int tid = threadIdx.x;
+    const int cc0 = c0 - pj0;
     for (int jj = 0; jj < w; ++jj) {
         const int col = c0 + jj;
         DzgCand best;
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel(int k, int pj0, int pnbw,
         best.k = -1;
         for (int i = col + tid; i < k; i += blockDim.x) {
             DzgCand c;
-            c.r = fabs(G[(long long)i * ldg + col]);
+            c.r = fabs(PN(i, cc0 + jj));
             c.k = i;
             if (c.r == c.r) best = dzg_better(best, c);
         }
@@ -312,21 +322,18 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel(int k, int pj0, int pnbw,
         const int p = s_p;
         // swap rows col <-> p inside the sub-panel, keep the pivot row in LDS
         if (tid < w) {
-            double *rc = G + (long long)col * ldg + c0 + tid;
-            double *rp = G + (long long)p * ldg + c0 + tid;
-            const double a = *rc, b = *rp;
-            *rc = b;
-            *rp = a;
+            const double a = PN(col, cc0 + tid), b = PN(p, cc0 + tid);
+            PN(col, cc0 + tid) = b;
+            PN(p, cc0 + tid) = a;
             s_pivrow[tid] = b;
         }
         __syncthreads();
         const double pv = s_pivrow[jj];
         const double rpv = pv != 0.0 ? 1.0 / pv : 0.0;
         for (int i = col + 1 + tid; i < k; i += blockDim.x) {
-            double *row = G + (long long)i * ldg + c0;
-            const double l = row[jj] * rpv;
-            row[jj] = l;
-            for (int c = jj + 1; c < w; ++c) row[c] = fma(-l, s_pivrow[c], row[c]);
+            const double l = PN(i, cc0 + jj) * rpv;
+            PN(i, cc0 + jj) = l;
+            for (int c = jj + 1; c < w; ++c) PN(i, cc0 + c) = fma(-l, s_pivrow[c], PN(i, cc0 + c));
         }
         __syncthreads();
     }
@@ -334,26 +341,53 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel(int k, int pj0, int pnbw,
     // right of the sub-panel take  U12' = L11^-1 A12'
     const int nother = pnbw - w;
     if (tid < nother) {
-        const int off = tid < (c0 - pj0) ? tid : tid + w; // skip the sub-panel's own columns
-        double *colp = G + pj0 + off;
+        const int off = tid < cc0 ? tid : tid + w; // skip the sub-panel's own columns
+        double *colp = Pn + (long long)off * ldp;
         for (int jj = 0; jj < w; ++jj) {
             const int r = c0 + jj, p = piv[r];
             if (p != r) {
-                const double a = colp[(long long)r * ldg], b = colp[(long long)p * ldg];
-                colp[(long long)r * ldg] = b;
-                colp[(long long)p * ldg] = a;
+                const double a = colp[r], b = colp[p];
+                colp[r] = b;
+                colp[p] = a;
             }
         }
-        if (pj0 + off >= c0 + w) { // right of the sub-panel
+        if (off >= cc0 + w) { // right of the sub-panel
             double y[SPW];
-            for (int i = 0; i < w; ++i) y[i] = colp[(long long)(c0 + i) * ldg];
+            for (int i = 0; i < w; ++i) y[i] = colp[c0 + i];
             for (int i = 1; i < w; ++i) {
                 double acc = y[i];
-                for (int j = 0; j < i; ++j)
-                    acc = fma(-G[(long long)(c0 + i) * ldg + c0 + j], y[j], acc);
+                for (int j = 0; j < i; ++j) acc = fma(-PN(c0 + i, cc0 + j), y[j], acc);
                 y[i] = acc;
             }
-            for (int i = 0; i < w; ++i) colp[(long long)(c0 + i) * ldg] = y[i];
+            for (int i = 0; i < w; ++i) colp[c0 + i] = y[i];
+        }
+    }
+}
+
+// Pn[cc][i] = G[i][pj0 + cc] for rows [pj0, k) (and back): 64 x 64 tiles through LDS, both sides
+// coalesced.  grid ceil((k - pj0) / 64)
+template <bool OUT>
+__global__ __launch_bounds__(256) void k_ref_panel_copy(int k, int pj0, int pnbw, double *__restrict__ G,
+                                                        long long ldg, double *__restrict__ Pn,
+                                                        long long ldp)
+{
+    __shared__ double s_t[NB][NB + 1];
+    const int r0 = pj0 + blockIdx.x * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+        const int hi = e / NB, lo = e % NB; // lo runs along the contiguous side of the SOURCE
+        if (OUT) {
+            if (hi < pnbw && r0 + lo < k) s_t[lo][hi] = PN(r0 + lo, hi);
+        } else {
+            if (r0 + hi < k && lo < pnbw) s_t[hi][lo] = G[(long long)(r0 + hi) * ldg + pj0 + lo];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+        const int hi = e / NB, lo = e % NB; // lo along the contiguous side of the TARGET
+        if (OUT) {
+            if (r0 + hi < k && lo < pnbw) G[(long long)(r0 + hi) * ldg + pj0 + lo] = s_t[hi][lo];
+        } else {
+            if (hi < pnbw && r0 + lo < k) PN(r0 + lo, hi) = s_t[lo][hi];
         }
     }
 }
@@ -365,10 +399,11 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel(int k, int pj0, int pnbw,
 // column reads of the global-memory version (one cache line per row and step) disappear.
 template <int SPR, int W> // SPR x W values per thread: 4 x 8 and 8 x 4 stay in registers
 __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int pnbw, int c0, int w,
-                                                           double *__restrict__ G, long long ldg,
+                                                           double *__restrict__ Pn, long long ldp,
                                                            int *__restrict__ piv,
                                                            int *__restrict__ singular)
 {
+    const int cc0 = c0 - pj0;
     // two workgroup barriers per elimination step (four at first: the block-wide max-loc brought
     // two of its own and the row exchange one more to protect its buffers): every LDS array is
     // double-buffered by the parity of the step, so nothing written in step jj + 1 can be something
@@ -378,21 +413,11 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
     __shared__ int s_ck[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double a[SPR][W];
-    // (a thread's row segment is W contiguous doubles, 16-byte aligned: 16-byte loads -- the rows of
-    // one load instruction are 64 different cache lines, and the one CU this kernel runs on spends
-    // 64 cycles of address processing per instruction whatever its width)
-    typedef double dbl2_t __attribute__((ext_vector_type(2)));
-    static_assert(W % 2 == 0, "sub-panel width");
 #pragma unroll
     for (int r = 0; r < SPR; ++r) {
         const int i = c0 + tid + 1024 * r;
-        const dbl2_t *src = reinterpret_cast<const dbl2_t *>(G + (long long)(i < k ? i : c0) * ldg + c0);
 #pragma unroll
-        for (int c = 0; c < W; c += 2) {
-            const dbl2_t v2 = src[c / 2];
-            a[r][c] = (i < k && c < w) ? v2.x : 0.0;
-            a[r][c + 1] = (i < k && c + 1 < w) ? v2.y : 0.0;
-        }
+        for (int c = 0; c < W; ++c) a[r][c] = (i < k && c < w) ? PN(i, cc0 + c) : 0.0;
     }
 #pragma unroll
     for (int jj = 0; jj < W; ++jj) {
@@ -466,18 +491,9 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
     for (int r = 0; r < SPR; ++r) {
         const int i = c0 + tid + 1024 * r;
         if (i < k) {
-            dbl2_t *dst = reinterpret_cast<dbl2_t *>(G + (long long)i * ldg + c0);
 #pragma unroll
-            for (int c = 0; c < W; c += 2) {
-                if (c + 1 < w) {
-                    dbl2_t v2;
-                    v2.x = a[r][c];
-                    v2.y = a[r][c + 1];
-                    dst[c / 2] = v2;
-                } else if (c < w) {
-                    G[(long long)i * ldg + c0 + c] = a[r][c];
-                }
-            }
+            for (int c = 0; c < W; ++c)
+                if (c < w) PN(i, cc0 + c) = a[r][c];
         }
     }
     __syncthreads();
@@ -487,16 +503,16 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
     // through memory (two dependent loads and two stores each) this tail was most of the kernel.
     const int nother = pnbw - w;
     if (tid < nother) {
-        const int off = tid < (c0 - pj0) ? tid : tid + w;
-        double *colp = G + pj0 + off;
+        const int off = tid < cc0 ? tid : tid + w;
+        double *colp = Pn + (long long)off * ldp;
         int pr[W];
         double top[W], piv_v[W]; // values at rows c0 + jj and at rows p_jj (before any swap)
 #pragma unroll
         for (int jj = 0; jj < W; ++jj) pr[jj] = jj < w ? piv[c0 + jj] : c0 + jj;
 #pragma unroll
         for (int jj = 0; jj < W; ++jj) {
-            top[jj] = jj < w ? colp[(long long)(c0 + jj) * ldg] : 0.0;
-            piv_v[jj] = jj < w ? colp[(long long)pr[jj] * ldg] : 0.0;
+            top[jj] = jj < w ? colp[c0 + jj] : 0.0;
+            piv_v[jj] = jj < w ? colp[pr[jj]] : 0.0;
         }
         // replay the swaps on the copies: a row's current value lives in top[] if it is one of the
         // first w rows, else in the piv_v[] slot of the FIRST step that names it
@@ -535,9 +551,9 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
 #pragma unroll
             for (int t = 0; t < W; ++t)
                 if (t < jj && pr[t] == pr[jj]) first = false;
-            if (first) colp[(long long)pr[jj] * ldg] = piv_v[jj];
+            if (first) colp[pr[jj]] = piv_v[jj];
         }
-        if (pj0 + off >= c0 + w) {
+        if (off >= cc0 + w) {
             double y[W];
 #pragma unroll
             for (int i = 0; i < W; ++i) y[i] = i < w ? top[i] : 0.0;
@@ -546,69 +562,66 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
                 double acc = y[i];
 #pragma unroll
                 for (int j = 0; j < W; ++j)
-                    if (j < i && i < w) acc = fma(-G[(long long)(c0 + i) * ldg + c0 + j], y[j], acc);
+                    if (j < i && i < w) acc = fma(-PN(c0 + i, cc0 + j), y[j], acc);
                 y[i] = acc;
             }
 #pragma unroll
             for (int i = 0; i < W; ++i)
-                if (i < w) colp[(long long)(c0 + i) * ldg] = y[i];
+                if (i < w) colp[c0 + i] = y[i];
         } else {
 #pragma unroll
             for (int i = 0; i < W; ++i)
-                if (i < w) colp[(long long)(c0 + i) * ldg] = top[i];
+                if (i < w) colp[c0 + i] = top[i];
         }
     }
 }
 
-// rows [c0 + w, k), panel columns [c0 + w, pj0 + pnbw):  A22' -= L21 * U12'.  One thread per row.
+// rows [c0 + w, k), panel columns [c0 + w, pj0 + pnbw):  A22' -= L21 * U12'.  One thread per row of
+// the compact panel and group of 8 columns: its w multipliers in registers, then column after
+// column (consecutive threads = consecutive rows of a column: full lines), U12' in LDS.
+// grid (ceil((k - c0 - w) / 256), ceil(columns / 8)): one thread per row over ALL columns left 32
+// workgroups for 8 192 rows, 17 us of dependent load-FMA-store per call.
 __global__ __launch_bounds__(256) void k_ref_subupdate(int k, int pj0, int pnbw, int c0, int w,
-                                                       double *__restrict__ G, long long ldg)
+                                                       double *__restrict__ Pn, long long ldp)
 {
-    // 32 lanes along a row (two columns each, 16-byte accesses), 8 rows per workgroup and pass: a
-    // wave touches 2 x 448 contiguous bytes per instruction.  (One thread per row walking its row
-    // column by column -- the first version -- made every instruction 64 separate cache lines.)
-    typedef double dbl2_t __attribute__((ext_vector_type(2)));
     __shared__ double s_u[SPW][NB];
-    const int right0 = c0 + w, nright = pj0 + pnbw - right0;
+    const int cc0 = c0 - pj0, ccr = cc0 + w, nright = pnbw - ccr;
     for (int e = threadIdx.x; e < w * nright; e += blockDim.x)
-        s_u[e / nright][e % nright] = G[(long long)(c0 + e / nright) * ldg + right0 + e % nright];
+        s_u[e / nright][e % nright] = PN(c0 + e / nright, ccr + e % nright);
     __syncthreads();
-    const int cl = 2 * (threadIdx.x & 31), rsub = threadIdx.x >> 5;
-    const int i = right0 + blockIdx.x * 8 + rsub;
-    if (i >= k || cl >= nright) return;
-    double *row = G + (long long)i * ldg;
+    const int i = c0 + w + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
     double l[SPW];
 #pragma unroll
-    for (int j = 0; j < SPW; ++j) l[j] = j < w ? row[c0 + j] : 0.0;
-    // right0 is even (sub-panels are 8 or 4 columns wide but for the last of a panel): 16-byte aligned
-    if (cl + 1 < nright && ((right0 & 1) == 0)) {
-        dbl2_t acc = *reinterpret_cast<dbl2_t *>(row + right0 + cl);
+    for (int j = 0; j < SPW; ++j) l[j] = j < w ? PN(i, cc0 + j) : 0.0;
+    const int cb = blockIdx.y * 8;
+    double acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = cb + c < nright ? PN(i, ccr + cb + c) : 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int cs = cb + c < nright ? cb + c : 0;
 #pragma unroll
         for (int j = 0; j < SPW; ++j)
-            if (j < w) {
-                acc.x = fma(-l[j], s_u[j][cl], acc.x);
-                acc.y = fma(-l[j], s_u[j][cl + 1], acc.y);
-            }
-        *reinterpret_cast<dbl2_t *>(row + right0 + cl) = acc;
-    } else {
-        for (int c = cl; c < nright && c < cl + 2; ++c) {
-            double acc = row[right0 + c];
-#pragma unroll
-            for (int j = 0; j < SPW; ++j)
-                if (j < w) acc = fma(-l[j], s_u[j][c], acc);
-            row[right0 + c] = acc;
-        }
+            if (j < w) acc[c] = fma(-l[j], s_u[j][cs], acc[c]);
     }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (cb + c < nright) PN(i, ccr + cb + c) = acc[c];
 }
 
-// apply the panel's row swaps to every column outside the panel of G and to all columns of X.
-// one thread per column.
+// apply the panel's row swaps to every column outside the panel of G and to the columns [0, j0)
+// of X.  X is kept in PIVOT ORDER of its columns (stored column c belongs to the original row that
+// sits in position c now): a swap of rows r and p then exchanges their entries left of the diagonal
+// only and the unit diagonal stays where it is -- what LAPACK does with the L factor itself -- so
+// that X stays unit lower triangular all through the forward substitution (k_ref_colperm puts
+// the columns back at the end).  one thread per column.
 __global__ __launch_bounds__(256) void k_ref_swap(int k, int j0, int nbw, double *__restrict__ G,
                                                   double *__restrict__ X, long long ldg,
                                                   const int *__restrict__ piv)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * k) return;
+    if (c >= k + j0) return;
     double *Mx = c < k ? G : X;
     const int col = c < k ? c : c - k;
     if (c < k && col >= j0 && col < j0 + nbw) return; // the panel swapped itself
@@ -628,9 +641,10 @@ __global__ __launch_bounds__(256) void k_ref_trsm_l(int j0, int nbw, const doubl
                                                     long long ldg, double *__restrict__ T,
                                                     long long ldt, int cbeg, int cend)
 {
-    __shared__ double s_l[NB][NB + 1];
+    // s_lt[j][i] = L[i][j]: the multipliers of elimination step j are contiguous (16-byte reads)
+    __shared__ __attribute__((aligned(16))) double s_lt[NB][NB];
     for (int e = threadIdx.x; e < nbw * nbw; e += blockDim.x)
-        s_l[e / nbw][e % nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
+        s_lt[e % nbw][e / nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
     __syncthreads();
     const int c = cbeg + blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cend) return;
@@ -638,12 +652,15 @@ __global__ __launch_bounds__(256) void k_ref_trsm_l(int j0, int nbw, const doubl
     if (FULL) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
+        // column by column (right-looking): once y[j] is final, the NB - 1 - j rows below take their
+        // term of it -- independent FMAs, where the row-by-row form is one chain of dependent FMAs
+        // per row with an LDS read in front of each (50 us per launch, one wave per CU).  Every
+        // y[i] still collects its terms in ascending j: the same bits.
 #pragma unroll
-        for (int i = 1; i < NB; ++i) {
-            double acc = y[i];
+        for (int j = 0; j < NB - 1; ++j) {
+            const double yj = y[j];
 #pragma unroll
-            for (int j = 0; j < i; ++j) acc = fma(-s_l[i][j], y[j], acc);
-            y[i] = acc;
+            for (int i = j + 1; i < NB; ++i) y[i] = fma(-s_lt[j][i], yj, y[i]);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(256) void k_ref_trsm_l(int j0, int nbw, const doubl
         for (int i = 0; i < nbw; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
         for (int i = 1; i < nbw; ++i) {
             double acc = y[i];
-            for (int j = 0; j < i; ++j) acc = fma(-s_l[i][j], y[j], acc);
+            for (int j = 0; j < i; ++j) acc = fma(-s_lt[j][i], y[j], acc);
             y[i] = acc;
         }
         for (int i = 0; i < nbw; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
@@ -664,9 +681,10 @@ __global__ __launch_bounds__(256) void k_ref_trsm_u(int j0, int nbw, const doubl
                                                     long long ldg, double *__restrict__ X,
                                                     long long ldx, int ncols)
 {
-    __shared__ double s_u[NB][NB + 1];
+    // s_ut[j][i] = U[i][j]: column j of U11 contiguous
+    __shared__ __attribute__((aligned(16))) double s_ut[NB][NB];
     for (int e = threadIdx.x; e < nbw * nbw; e += blockDim.x)
-        s_u[e / nbw][e % nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
+        s_ut[e % nbw][e / nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
     __syncthreads();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
@@ -674,24 +692,74 @@ __global__ __launch_bounds__(256) void k_ref_trsm_u(int j0, int nbw, const doubl
     if (FULL) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
+        // column by column from the last (see k_ref_trsm_l): y[j] final, then its term leaves
+        // the j rows above -- independent FMAs
 #pragma unroll
-        for (int i = NB - 1; i >= 0; --i) {
-            double acc = y[i];
+        for (int j = NB - 1; j >= 0; --j) {
+            const double yj = y[j] / s_ut[j][j];
+            y[j] = yj;
 #pragma unroll
-            for (int j = i + 1; j < NB; ++j) acc = fma(-s_u[i][j], y[j], acc);
-            y[i] = acc / s_u[i][i];
+            for (int i = 0; i < j; ++i) y[i] = fma(-s_ut[j][i], yj, y[i]);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
     } else {
         for (int i = 0; i < nbw; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
-        for (int i = nbw - 1; i >= 0; --i) {
-            double acc = y[i];
-            for (int j = i + 1; j < nbw; ++j) acc = fma(-s_u[i][j], y[j], acc);
-            y[i] = acc / s_u[i][i];
+        for (int j = nbw - 1; j >= 0; --j) {
+            const double yj = y[j] / s_ut[j][j];
+            y[j] = yj;
+            for (int i = 0; i < j; ++i) y[i] = fma(-s_ut[j][i], yj, y[i]);
         }
         for (int i = 0; i < nbw; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
     }
+}
+
+// orig[c] = the original row whose unit vector stored column c of X started as: the row swaps of
+// the factorisation replayed on the identity list.  One thread: k dependent steps, in LDS while k
+// ints fit (use_lds), in global memory beyond.
+__global__ __launch_bounds__(256) void k_ref_perm(int k, const int *__restrict__ piv,
+                                                  int *__restrict__ orig, int use_lds)
+{
+    extern __shared__ int s_o[];
+    if (use_lds) {
+        for (int i = threadIdx.x; i < k; i += blockDim.x) s_o[i] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int pn = piv[0];
+            for (int c = 0; c < k; ++c) {
+                const int p = pn;
+                if (c + 1 < k) pn = piv[c + 1]; // (the next pivot is on its way during this step)
+                const int a = s_o[c], b = s_o[p];
+                s_o[c] = b;
+                s_o[p] = a;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < k; i += blockDim.x) orig[i] = s_o[i];
+    } else {
+        for (int i = threadIdx.x; i < k; i += blockDim.x) orig[i] = i;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            volatile int *o = orig;
+            for (int c = 0; c < k; ++c) {
+                const int p = piv[c];
+                const int a = o[c], b = o[p];
+                o[c] = b;
+                o[p] = a;
+            }
+        }
+    }
+}
+
+// Y[r][orig[c]] = X[r][c]: the columns of the finished inverse back in their own order.
+// grid (ceil(k / 256), k)
+__global__ __launch_bounds__(256) void k_ref_colperm(int k, const double *__restrict__ X,
+                                                     const int *__restrict__ orig,
+                                                     double *__restrict__ Y, long long ld)
+{
+    const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k) Y[(long long)r * ld + orig[c]] = X[(long long)r * ld + c];
 }
 
 // Binv0[spos[b]][a] = X[b][a]   grid (ceil(k/256), k)
@@ -752,7 +820,7 @@ static void gemm_sub(int M, int N, int K, const double *A, long long lda, const 
                        K, A, lda, B, ldb, C, ldc, (const int *)nullptr);
 }
 
-void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, long long ldg,
+void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, long long ldg,
                          int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
                          int *singular, hipStream_t st)
 {
@@ -770,6 +838,10 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
         for (int j0 = 0; j0 < k; j0 += NB) {
             const int nbw = (k - j0) < NB ? (k - j0) : NB;
             const int rest = k - j0 - nbw;
+            // the panel in its compact column-major copy (leading dimension ldg: >= k rows)
+            const long long ldp = ldg;
+            hipLaunchKernelGGL((k_ref_panel_copy<false>), dim3((k - j0 + NB - 1) / NB), dim3(256), 0, st, k,
+                               j0, nbw, G, ldg, Pn, ldp);
             // sub-panels: 8 columns while the active rows fit 4 per thread, 4 columns up to 8 rows
             // per thread (both all-register), the global-memory kernel beyond 8192 active rows
             for (int c0 = j0; c0 < j0 + nbw;) {
@@ -778,35 +850,39 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
                 const int w = (j0 + nbw - c0) < cap ? (j0 + nbw - c0) : cap;
                 if (rows <= 1024 * 4)
                     hipLaunchKernelGGL((k_ref_subpanel_reg<4, 8>), dim3(1), dim3(1024), 0, st, k, j0,
-                                       nbw, c0, w, G, ldg, piv, singular);
+                                       nbw, c0, w, Pn, ldp, piv, singular);
                 else if (rows <= 1024 * 8)
                     hipLaunchKernelGGL((k_ref_subpanel_reg<8, 4>), dim3(1), dim3(1024), 0, st, k, j0,
-                                       nbw, c0, w, G, ldg, piv, singular);
+                                       nbw, c0, w, Pn, ldp, piv, singular);
                 else
                     hipLaunchKernelGGL(k_ref_subpanel, dim3(1), dim3(1024), 0, st, k, j0, nbw, c0, w,
-                                       G, ldg, piv, singular);
+                                       Pn, ldp, piv, singular);
                 const int below = k - c0 - w;
                 if (below > 0 && c0 + w < j0 + nbw)
-                    hipLaunchKernelGGL(k_ref_subupdate, dim3((below + 7) / 8), dim3(256), 0, st,
-                                       k, j0, nbw, c0, w, G, ldg);
+                    hipLaunchKernelGGL(k_ref_subupdate,
+                                       dim3((below + 255) / 256, (j0 + nbw - c0 - w + 7) / 8), dim3(256), 0,
+                                       st, k, j0, nbw, c0, w, Pn, ldp);
                 c0 += w;
             }
-            hipLaunchKernelGGL(k_ref_swap, dim3((2 * k + 255) / 256), dim3(256), 0, st, k, j0, nbw, G,
+            hipLaunchKernelGGL((k_ref_panel_copy<true>), dim3((k - j0 + NB - 1) / NB), dim3(256), 0, st, k,
+                               j0, nbw, G, ldg, Pn, ldp);
+            hipLaunchKernelGGL(k_ref_swap, dim3((k + j0 + 255) / 256), dim3(256), 0, st, k, j0, nbw, G,
                                X, ldg, piv);
             auto trsm_l = nbw == NB ? k_ref_trsm_l<true> : k_ref_trsm_l<false>;
             if (rest > 0) // U12 = L11^-1 A12
                 hipLaunchKernelGGL(trsm_l, dim3((rest + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, G,
                                    ldg, j0 + nbw, k);
-            // forward substitution block of X (all k columns)
-            hipLaunchKernelGGL(trsm_l, dim3((k + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, X, ldg,
-                               0, k);
+            // forward substitution block of X: unit lower triangular in pivot order of its columns
+            // (k_ref_swap), so only the columns [0, j0 + nbw) hold anything
+            hipLaunchKernelGGL(trsm_l, dim3((j0 + nbw + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, X,
+                               ldg, 0, j0 + nbw);
             if (rest > 0) {
                 const double *L21 = G + (long long)(j0 + nbw) * ldg + j0;
                 // A22 -= L21 * U12
                 gemm_sub(rest, rest, nbw, L21, ldg, G + (long long)j0 * ldg + j0 + nbw, ldg,
                          G + (long long)(j0 + nbw) * ldg + j0 + nbw, ldg, st);
-                // X2 -= L21 * X1
-                gemm_sub(rest, k, nbw, L21, ldg, X + (long long)j0 * ldg, ldg,
+                // X2 -= L21 * X1 (columns [0, j0 + nbw))
+                gemm_sub(rest, j0 + nbw, nbw, L21, ldg, X + (long long)j0 * ldg, ldg,
                          X + (long long)(j0 + nbw) * ldg, ldg, st);
             }
         }
@@ -819,35 +895,51 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, l
             if (j0 > 0) // X[0..j0) -= U01 * X1
                 gemm_sub(j0, k, nbw, G + j0, ldg, X + (long long)j0 * ldg, ldg, X, ldg, st);
         }
+        // ---- the columns of X back from pivot order: G^-1 = U^-1 L^-1 P.  G's factors are done
+        // with: the permuted inverse goes there and X becomes the free panel
+        {
+            static const size_t lds_cap = 150 * 1024; // of the CU's 160 KB
+            static const hipError_t attr = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(k_ref_perm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                (int)lds_cap);
+            const size_t need = sizeof(int) * (size_t)k;
+            const int use_lds = attr == hipSuccess && need <= lds_cap;
+            hipLaunchKernelGGL(k_ref_perm, dim3(1), dim3(256), use_lds ? need : 0, st, k, piv, lslot,
+                               use_lds);
+            hipLaunchKernelGGL(k_ref_colperm, dim3((k + 255) / 256, k), dim3(256), 0, st, k, X, lslot, G,
+                               ldg);
+        }
+        const double *Xf = G; // the finished inverse
+        double *Wk = X;       // free
         if (d.spb) {
             // sparse-basis mode keeps the k x k block only (k_sparse.hip); rows in position order
-            dzg_launch_sp_ref_copy(d, k, X, ldg, st);
+            dzg_launch_sp_ref_copy(d, k, Xf, ldg, st);
             hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);
             return;
         }
         // ---- Binv0 rows of the structural positions
-        hipLaunchKernelGGL(k_ref_scatter, dim3((k + 255) / 256, k), dim3(256), 0, st, k, X, ldg, spos,
+        hipLaunchKernelGGL(k_ref_scatter, dim3((k + 255) / 256, k), dim3(256), 0, st, k, Xf, ldg, spos,
                            d.binv, d.ldb);
-        // ---- Binv0 rows of the basic slacks: -A[r', S] * X   (G is free now: reuse it for A[r', S])
+        // ---- Binv0 rows of the basic slacks: -A[r', S] * X   (A[r', S] goes into the free panel)
         if (nl > 0) {
             if (d.csc) {
-                hipMemsetAsync(G, 0, sizeof(double) * (size_t)nl * (size_t)ldg, st);
+                hipMemsetAsync(Wk, 0, sizeof(double) * (size_t)nl * (size_t)ldg, st);
                 hipLaunchKernelGGL(k_ref_lslot, dim3((d.m + 255) / 256), dim3(256), 0, st, d.m, nl, lrow,
                                    lslot);
                 hipLaunchKernelGGL(k_ref_lslot_fill, dim3((nl + 255) / 256), dim3(256), 0, st, nl, lrow,
                                    lslot);
                 hipLaunchKernelGGL(k_ref_scatter_csc, dim3(k), dim3(256), 0, st, k, d.cptr, d.ridx,
-                                   d.cval, d.col0, scode, lslot, G, ldg);
+                                   d.cval, d.col0, scode, lslot, Wk, ldg);
             } else {
                 hipLaunchKernelGGL(k_ref_gather_slack, dim3((k + 255) / 256, nl), dim3(256), 0, st, k,
-                                   d.A, d.lda, d.col0, lrow, scode, G, ldg);
+                                   d.A, d.lda, d.col0, lrow, scode, Wk, ldg);
             }
             if ((long long)((nl + 63) / 64) * ((k + 63) / 64) >= 512 && !std::getenv("DZG_REF_GEMM_STRIPS"))
                 hipLaunchKernelGGL((k_ref_gemm_lds<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
-                                   nl, k, k, G, ldg, X, ldg, d.binv, d.ldb, (const int *)lpos);
+                                   nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
             else
                 hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
-                                   nl, k, k, G, ldg, X, ldg, d.binv, d.ldb, (const int *)lpos);
+                                   nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
         }
     }
     hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);

@@ -107,6 +107,13 @@ typedef struct {
     const int64_t *col_ptr;  /* n_struct + 1                                            */
     const int32_t *row_idx;  /* nnz                                                     */
     const double *val;       /* nnz                                                     */
+    /* The perturbation vectors of the parametric method (Simplex.x_bar, Simplex.z_bar,
+     * src/simplex.rs:84-112).  NULL = all ones, as Simplex::new sets them (src/simplex.rs:219-220).
+     * Given together with a non-slack `basis`, its `x` and `z`, they RESUME a solve from the state
+     * a dzg_result handed back (basis, nonbasis, x, xbar, z, zbar): the basis is factorised on the
+     * device and the loop goes on where it stopped. */
+    const double *xbar;      /* m    or NULL                                             */
+    const double *zbar;      /* n-m  or NULL                                             */
 } dzg_lp;
 
 typedef struct {

@@ -564,6 +564,43 @@ def test_sparse_fast_warm_start(core):
     assert _log(fast) == _log(want)
 
 
+@pytest.mark.parametrize("seed", [91, 92, 93])
+def test_a_solve_resumes_from_the_six_state_arrays(core, seed):
+    """dzg_lp.xbar / zbar (Simplex.x_bar, z_bar): what a result hands back -- basis, nonbasis, x,
+    xbar, z, zbar -- is the whole state of the reference's loop (src/simplex.rs:226-236 factorises
+    from scratch every iteration), so a STRICT solve stopped after N pivots and resumed in a NEW
+    solver takes the oracle's remaining pivots and ends on the oracle's bits; FAST (dense and the
+    sparse-basis path: the basis is factorised on the device at creation) takes the same pivots."""
+    a, b, c = core.gen_dense_lp(seed=seed, m=40, n_struct=70)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    stop = want.iterations // 2
+    assert stop >= 5
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    part = core.solve(lp, numerics=core.STRICT, max_iter=stop)
+    assert part.status == "iter_limit" and part.iterations == stop
+    assert not (np.all(part.xbar == 1.0) and np.all(part.zbar == 1.0))
+    rest = core.solve(core.resumed_from(lp, part), numerics=core.STRICT)
+    assert rest.status == want.status
+    assert _log(part) + _log(rest) == _log(want)
+    assert np.array_equal(rest.basis, want.basis)
+    for name in ("x", "xbar", "z", "zbar"):
+        assert_bit_equal(getattr(rest, name), getattr(want, name), name)
+    assert rest.objective == want.objective
+    fast = core.solve(core.resumed_from(lp, part), numerics=core.FAST, poll_interval=8)
+    assert fast.status == want.status and fast.refactors >= 1
+    assert _log(part) + _log(fast) == _log(want)
+    assert abs(fast.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+    # the sparse-basis path, stopped and resumed in FAST numerics
+    lp_s, want_s = _oracle_sparse(core, seed, 70, 180, 4)
+    half = core.solve(lp_s, numerics=core.FAST, max_iter=want_s.iterations // 2, poll_interval=8)
+    assert half.status == "iter_limit" and half.dense_columns > 0
+    tail = core.solve(core.resumed_from(lp_s, half), numerics=core.FAST, poll_interval=8)
+    assert tail.status == want_s.status
+    assert _log(half) + _log(tail) == _log(want_s)
+    if want_s.status == "optimal":
+        assert abs(tail.objective - want_s.objective) <= 1e-9 * max(1.0, abs(want_s.objective))
+
+
 # ------------------------------------------------------------------ complete solves vs the oracle
 def _oracle_log_fixtures():
     import glob
