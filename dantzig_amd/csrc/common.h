@@ -415,7 +415,8 @@ void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st);
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st);
 void dzg_launch_refactor_lists(const DzgDev &d, int *spos, int *scode, int *lpos, int *lrow,
                                int *counts, hipStream_t st);
-void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, long long ldg,
+void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, double *Tri,
+                         long long ldg,
                          int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
                          int *singular, hipStream_t st);
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);

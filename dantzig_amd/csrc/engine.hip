@@ -94,7 +94,8 @@ struct dzg_solver {
     double solve_ms = 0.0;
     int since_flush = 0; // iterations enqueued since the eta file was last folded into Binv0
     // refactorisation workspace (FAST, opts.refactor_interval != 0)
-    double *rfG = nullptr, *rfX = nullptr, *rfPn = nullptr; // (rfPn: one 64-column panel, column-major)
+    double *rfG = nullptr, *rfX = nullptr, *rfPn = nullptr, *rfTri = nullptr; // (rfPn: one 64-column panel,
+                                                                 // column-major; rfTri: L11^-1, U11^-1 per panel)
     long long rf_ld = 0;
     int *rf_piv = nullptr, *rf_spos = nullptr, *rf_scode = nullptr, *rf_lpos = nullptr,
         *rf_lrow = nullptr, *rf_counts = nullptr, *rf_lslot = nullptr;
@@ -826,6 +827,7 @@ static int refactor_workspace(dzg_solver *s)
     TRY(dev_alloc(s, &g, m * (size_t)s->rf_ld));
     TRY(dev_alloc(s, &s->rfX, m * (size_t)s->rf_ld));
     TRY(dev_alloc(s, &s->rfPn, (size_t)64 * (size_t)s->rf_ld));
+    TRY(dev_alloc(s, &s->rfTri, ((m + 63) / 64) * (size_t)(2 * 64 * 64)));
     TRY(dev_alloc(s, &s->rf_piv, m)); TRY(dev_alloc(s, &s->rf_spos, m));
     TRY(dev_alloc(s, &s->rf_scode, m)); TRY(dev_alloc(s, &s->rf_lpos, m));
     TRY(dev_alloc(s, &s->rf_lrow, m)); TRY(dev_alloc(s, &s->rf_counts, 4));
@@ -847,7 +849,7 @@ static int refactor_now(dzg_solver *s)
         return 0;
     if (counts[0] != s->h_ctl->ncompact)
         return fail(DZG_E_DEVICE, "refactor: structural basics != dense columns");
-    dzg_launch_refactor(d, counts[0], counts[1], s->rfG, s->rfX, s->rfPn, s->rf_ld, s->rf_piv, s->rf_spos,
+    dzg_launch_refactor(d, counts[0], counts[1], s->rfG, s->rfX, s->rfPn, s->rfTri, s->rf_ld, s->rf_piv, s->rf_spos,
                         s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_lslot, s->rf_counts + 2, s->st);
     s->since_flush = 0;
     s->h_ctl->neta = 0; // the refactorisation empties the eta file (k_ref_done)

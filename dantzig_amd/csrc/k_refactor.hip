@@ -393,10 +393,55 @@ __global__ __launch_bounds__(256) void k_ref_panel_copy(int k, int pj0, int pnbw
 }
 
 // The same sub-panel step with the active rows held in REGISTERS: thread t owns rows
-// c0 + t, c0 + t + 1024, ... (SPR of them at most, i.e. k - c0 <= 1024 * SPR), loads their SPW
+// c0 + t, c0 + t + 1024, ... (SPR of them at most, i.e. k - c0 <= 1024 * SPR), loads their W
 // values once, runs the w elimination steps on registers -- per step one block-wide max-loc, one
-// exchange of the two swapped rows through LDS -- and writes them back once.  The strided
-// column reads of the global-memory version (one cache line per row and step) disappear.
+// exchange of the two swapped rows through LDS -- and writes them back once.
+//
+// The kernel runs on ONE compute unit, 4 waves per SIMD, and a wave issues one instruction every
+// four cycles at best: an elimination step costs what its instruction count says.  The first
+// version spent some 1 000 instructions per step and wave (3 us): every row of every thread asked
+// "am I row col? am I row p? am I below col?" with its own compare-select or exec-mask branch,
+// and the max-loc went through 36 ds_bpermute.  Now: the two rows that trade places are handled
+// inside wave-uniform branches (the pivot row's wave is read off the scalar p; row col is always
+// thread jj's first row), only a thread's FIRST row can lie above the diagonal (its other rows sit
+// 1 024 positions further down), rows beyond k are zero rows that eliminate to zero, and the
+// max-loc runs on DPP row operations (4 levels inside a row of 16 lanes; 2 ds_bpermute levels
+// across rows; the 16 wave winners again as one row of 16).
+struct DzgPiv {
+    double v; // |a|, or -1: no candidate
+    int k;
+};
+__device__ __forceinline__ DzgPiv dzg_piv_better(DzgPiv a, DzgPiv b)
+{
+    // the first maximum of |.| in row order: larger value, on equal values the lower row
+    const bool bw = b.v > a.v || (b.v == a.v && b.k < a.k);
+    DzgPiv r;
+    r.v = bw ? b.v : a.v;
+    r.k = bw ? b.k : a.k;
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ DzgPiv dzg_piv_dpp(DzgPiv c)
+{
+    int lo = __double2loint(c.v), hi = __double2hiint(c.v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    DzgPiv o;
+    o.v = __hiloint2double(hi, lo);
+    o.k = __builtin_amdgcn_update_dpp(c.k, c.k, CTRL, 0xf, 0xf, false);
+    return dzg_piv_better(c, o);
+}
+// every lane of a row of 16 ends with the row's winner: quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror (the operation is commutative and idempotent)
+__device__ __forceinline__ DzgPiv dzg_piv_row16(DzgPiv c)
+{
+    c = dzg_piv_dpp<0xB1>(c);
+    c = dzg_piv_dpp<0x4E>(c);
+    c = dzg_piv_dpp<0x141>(c);
+    c = dzg_piv_dpp<0x140>(c);
+    return c;
+}
+
 template <int SPR, int W> // SPR x W values per thread: 4 x 8 and 8 x 4 stay in registers
 __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int pnbw, int c0, int w,
                                                            double *__restrict__ Pn, long long ldp,
@@ -404,13 +449,14 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
                                                            int *__restrict__ singular)
 {
     const int cc0 = c0 - pj0;
-    // two workgroup barriers per elimination step (four at first: the block-wide max-loc brought
-    // two of its own and the row exchange one more to protect its buffers): every LDS array is
-    // double-buffered by the parity of the step, so nothing written in step jj + 1 can be something
-    // a thread still reads in step jj - 1
+    // two workgroup barriers per elimination step: every LDS array the steps use is double-buffered
+    // by the parity of the step, so nothing written in step jj + 1 can be something a thread still
+    // reads in step jj - 1
     __shared__ double s_rowc[2][W], s_rowp[2][W];
-    __shared__ double s_cr[2][16];
+    __shared__ double s_cv[2][16];
     __shared__ int s_ck[2][16];
+    __shared__ int s_piv[W];
+    __shared__ double s_l11[W][W];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double a[SPR][W];
 #pragma unroll
@@ -423,68 +469,95 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
     for (int jj = 0; jj < W; ++jj) {
         if (jj >= w) break;
         const int col = c0 + jj;
-        DzgCand best;
-        best.r = 0.0;
+        DzgPiv best;
+        best.v = -1.0;
         best.k = -1;
 #pragma unroll
         for (int r = 0; r < SPR; ++r) {
             const int i = c0 + tid + 1024 * r;
-            if (i >= col && i < k) {
-                DzgCand c;
-                c.r = fabs(a[r][jj]);
-                c.k = i;
-                if (c.r == c.r) best = dzg_better(best, c);
+            const double x = a[r][jj];
+            bool ok = i < k && x == x;
+            if (r == 0) ok = ok && tid >= jj; // (rows c0 .. col - 1 are done)
+            const double v = ok ? fabs(x) : -1.0;
+            if (v > best.v) { // rows in ascending order: the first maximum stays
+                best.v = v;
+                best.k = i;
             }
         }
         const int buf = jj & 1;
-        best = dzg_wave_best(best);
+        best = dzg_piv_row16(best);
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            DzgPiv o;
+            o.v = __shfl_xor(best.v, off, DZG_WAVE);
+            o.k = __shfl_xor(best.k, off, DZG_WAVE);
+            best = dzg_piv_better(best, o);
+        }
         if (lane == 0) {
-            s_cr[buf][wave] = best.r;
+            s_cv[buf][wave] = best.v;
             s_ck[buf][wave] = best.k;
         }
         __syncthreads();
-        {
-            DzgCand o;
-            o.r = lane < 16 ? s_cr[buf][lane] : 0.0;
-            o.k = lane < 16 ? s_ck[buf][lane] : -1;
-            best = dzg_wave_best(o); // (the same fan-in as dzg_block_best: 16 wave winners)
-        }
-        const int p = best.k >= 0 ? best.k : col;
+        best.v = s_cv[buf][lane & 15];
+        best.k = s_ck[buf][lane & 15];
+        best = dzg_piv_row16(best); // the 16 wave winners: one row of 16 lanes, in every row
+        const int p = __builtin_amdgcn_readfirstlane(best.k >= 0 ? best.k : col);
         if (tid == 0) {
             piv[col] = p;
-            if (!(best.r > 0.0)) *singular = 1;
+            s_piv[jj] = p;
+            if (!(best.v > 0.0)) *singular = 1;
         }
-        // the two rows trade places through LDS (row col lives in thread jj's slot 0)
+        // the two rows trade places through LDS: row col is thread jj's first row, row p sits in
+        // thread pt, slot ps
+        const int pt = (p - c0) & 1023, ps = (p - c0) >> 10;
+        if (wave == 0) {
+            if (tid == jj)
 #pragma unroll
-        for (int r = 0; r < SPR; ++r) {
-            const int i = c0 + tid + 1024 * r;
-            if (i == col)
+                for (int c = 0; c < W; ++c) s_rowc[buf][c] = a[0][c];
+        }
+        if (wave == (pt >> 6)) {
+            if (tid == pt)
 #pragma unroll
-                for (int c = 0; c < W; ++c) s_rowc[buf][c] = a[r][c];
-            if (i == p)
+                for (int r = 0; r < SPR; ++r)
+                    if (r == ps)
 #pragma unroll
-                for (int c = 0; c < W; ++c) s_rowp[buf][c] = a[r][c];
+                        for (int c = 0; c < W; ++c) s_rowp[buf][c] = a[r][c];
         }
         __syncthreads();
-        const double pv = s_rowp[buf][jj];
+        double prow[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) prow[c] = s_rowp[buf][c];
+        const double pv = prow[jj];
         const double rpv = pv != 0.0 ? 1.0 / pv : 0.0;
+        if (wave == 0) {
+            if (tid == jj)
 #pragma unroll
-        for (int r = 0; r < SPR; ++r) {
-            const int i = c0 + tid + 1024 * r;
-            if (i == col) {
+                for (int c = 0; c < W; ++c) a[0][c] = prow[c];
+        }
+        if (p != col && wave == (pt >> 6)) {
+            if (tid == pt)
 #pragma unroll
-                for (int c = 0; c < W; ++c) a[r][c] = s_rowp[buf][c];
-            } else if (i == p) { // p != col here
+                for (int r = 0; r < SPR; ++r)
+                    if (r == ps)
 #pragma unroll
-                for (int c = 0; c < W; ++c) a[r][c] = s_rowc[buf][c];
-            }
-            if (i > col && i < k) {
-                const double l = a[r][jj] * rpv;
-                a[r][jj] = l;
+                        for (int c = 0; c < W; ++c) a[r][c] = s_rowc[buf][c];
+        }
+        // eliminate below the diagonal: a thread's rows 1 .. SPR - 1 always are; rows beyond k
+        // are zero rows (never stored, never candidates)
+        if (tid > jj) {
+            const double l = a[0][jj] * rpv;
+            a[0][jj] = l;
 #pragma unroll
-                for (int c = 0; c < W; ++c)
-                    if (c > jj) a[r][c] = fma(-l, s_rowp[buf][c], a[r][c]);
-            }
+            for (int c = 0; c < W; ++c)
+                if (c > jj) a[0][c] = fma(-l, prow[c], a[0][c]);
+        }
+#pragma unroll
+        for (int r = 1; r < SPR; ++r) {
+            const double l = a[r][jj] * rpv;
+            a[r][jj] = l;
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (c > jj) a[r][c] = fma(-l, prow[c], a[r][c]);
         }
     }
 #pragma unroll
@@ -496,11 +569,15 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
                 if (c < w) PN(i, cc0 + c) = a[r][c];
         }
     }
+    if (tid < w) // the sub-panel's own triangle for the tail below (rows c0 .. c0 + w - 1)
+#pragma unroll
+        for (int c = 0; c < W; ++c) s_l11[tid][c] = a[0][c];
     __syncthreads();
     // the other columns of the enclosing panel: row swaps, then U12' = L11^-1 A12' (as above).
     // The w swaps are applied to REGISTER copies of the (at most 2 w) rows they touch -- rows
     // c0 .. c0 + w - 1 and the pivot rows -- fetched together: taken one swap after the other
     // through memory (two dependent loads and two stores each) this tail was most of the kernel.
+    // Pivots and triangle come from LDS: one trip to memory for the values, one back.
     const int nother = pnbw - w;
     if (tid < nother) {
         const int off = tid < cc0 ? tid : tid + w;
@@ -508,7 +585,7 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
         int pr[W];
         double top[W], piv_v[W]; // values at rows c0 + jj and at rows p_jj (before any swap)
 #pragma unroll
-        for (int jj = 0; jj < W; ++jj) pr[jj] = jj < w ? piv[c0 + jj] : c0 + jj;
+        for (int jj = 0; jj < W; ++jj) pr[jj] = jj < w ? s_piv[jj] : c0 + jj;
 #pragma unroll
         for (int jj = 0; jj < W; ++jj) {
             top[jj] = jj < w ? colp[c0 + jj] : 0.0;
@@ -562,7 +639,7 @@ __global__ __launch_bounds__(1024) void k_ref_subpanel_reg(int k, int pj0, int p
                 double acc = y[i];
 #pragma unroll
                 for (int j = 0; j < W; ++j)
-                    if (j < i && i < w) acc = fma(-PN(c0 + i, cc0 + j), y[j], acc);
+                    if (j < i && i < w) acc = fma(-s_l11[i][j], y[j], acc);
                 y[i] = acc;
             }
 #pragma unroll
@@ -616,10 +693,52 @@ __global__ __launch_bounds__(256) void k_ref_subupdate(int k, int pj0, int pnbw,
 // only and the unit diagonal stays where it is -- what LAPACK does with the L factor itself -- so
 // that X stays unit lower triangular all through the forward substitution (k_ref_colperm puts
 // the columns back at the end).  one thread per column.
+//
+// Two more workgroups ride along when the panel is full (tri != nullptr): one wave each inverts the
+// panel's diagonal blocks -- L11 (unit lower) and U11 -- column by column in registers, into
+// tri[0..4096) and tri[4096..8192) (row-major 64 x 64).  The block substitutions X1 <- L11^-1 X1,
+// U12 <- L11^-1 A12 and X1 <- U11^-1 X1 then are products on the matrix cores (k_ref_tri_apply):
+// as substitutions, one thread per column, they were 64 dependent steps of LDS-read-then-FMA with
+// one wave per CU -- 51-60 us per launch, 20 ms of a refactorisation at k = 8192.  The inversions
+// are the same chains, but two waves of them per panel, beside the swaps instead of after them.
 __global__ __launch_bounds__(256) void k_ref_swap(int k, int j0, int nbw, double *__restrict__ G,
                                                   double *__restrict__ X, long long ldg,
-                                                  const int *__restrict__ piv)
+                                                  const int *__restrict__ piv, double *__restrict__ tri)
 {
+    const int nswap = (k + j0 + 255) / 256;
+    if ((int)blockIdx.x >= nswap) { // (only launched with tri != nullptr and nbw == NB)
+        __shared__ __attribute__((aligned(16))) double s_t[NB][NB];
+        const bool upper = (int)blockIdx.x == nswap + 1;
+        // s_t[j][i] = M[i][j]: column j of the triangle contiguous
+        for (int e = threadIdx.x; e < NB * NB; e += blockDim.x)
+            s_t[e % NB][e / NB] = G[(long long)(j0 + e / NB) * ldg + j0 + e % NB];
+        __syncthreads();
+        if (threadIdx.x >= NB) return;
+        const int c = threadIdx.x; // column c of the inverse: M y = e_c
+        double y[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) y[i] = i == c ? 1.0 : 0.0;
+        if (!upper) {
+#pragma unroll
+            for (int j = 0; j < NB - 1; ++j) {
+                const double yj = y[j];
+#pragma unroll
+                for (int i = j + 1; i < NB; ++i) y[i] = fma(-s_t[j][i], yj, y[i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                const double yj = y[j] / s_t[j][j];
+                y[j] = yj;
+#pragma unroll
+                for (int i = 0; i < j; ++i) y[i] = fma(-s_t[j][i], yj, y[i]);
+            }
+        }
+        double *out = tri + (upper ? NB * NB : 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) out[i * NB + c] = y[i];
+        return;
+    }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= k + j0) return;
     double *Mx = c < k ? G : X;
@@ -711,6 +830,52 @@ __global__ __launch_bounds__(256) void k_ref_trsm_u(int j0, int nbw, const doubl
             for (int i = 0; i < j; ++i) y[i] = fma(-s_ut[j][i], yj, y[i]);
         }
         for (int i = 0; i < nbw; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
+    }
+}
+
+// T[row0 .. row0 + 64, cbeg .. cend) <- Minv * T[...] in place, Minv a 64 x 64 block inverse
+// (k_ref_swap), on the matrix cores.  A workgroup owns 64 columns: their 64 x 64 tile of T goes into
+// LDS whole before anything is written back, so the product may overwrite its own operand.  Lane
+// maps as in k_ref_gemm.  grid ceil((cend - cbeg) / 64)
+__global__ __launch_bounds__(256) void k_ref_tri_apply(const double *__restrict__ Minv,
+                                                       double *__restrict__ T, long long ldt, int row0,
+                                                       int cbeg, int cend)
+{
+    __shared__ __attribute__((aligned(16))) double s_b[NB][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = cbeg + blockIdx.x * 64;
+    const int li = lane & 15, lk = lane >> 4;
+    const int b_k = tid >> 5, b_c = 2 * (tid & 31);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int kk = b_k + 8 * u, c = c0 + b_c;
+        const double *p = T + (long long)(row0 + kk) * ldt;
+        double2r_t w;
+        w.x = c < cend ? p[c] : 0.0;
+        w.y = c + 1 < cend ? p[c + 1] : 0.0;
+        *reinterpret_cast<double2r_t *>(&s_b[kk][b_c]) = w;
+    }
+    double av[16];
+    const double *ap = Minv + (16 * wave + li) * NB;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) av[s] = ap[4 * s + lk];
+    __syncthreads();
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], s_b[4 * s + lk][16 * j + li], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = row0 + 16 * wave + lk + 4 * g, col = c0 + 16 * j + li;
+            if (col < cend) T[(long long)row * ldt + col] = acc[j][g];
+        }
     }
 }
 
@@ -820,7 +985,8 @@ static void gemm_sub(int M, int N, int K, const double *A, long long lda, const 
                        K, A, lda, B, ldb, C, ldc, (const int *)nullptr);
 }
 
-void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, long long ldg,
+void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, double *Tri,
+                         long long ldg,
                          int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
                          int *singular, hipStream_t st)
 {
@@ -834,12 +1000,14 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, d
             hipLaunchKernelGGL(k_ref_gather, dim3((k + 255) / 256, k), dim3(256), 0, st, k, d.A, d.lda,
                                d.col0, d.drow, scode, G, X, ldg);
         }
-        // ---- LU of G with the forward substitution of X riding along
-        for (int j0 = 0; j0 < k; j0 += NB) {
-            const int nbw = (k - j0) < NB ? (k - j0) : NB;
-            const int rest = k - j0 - nbw;
-            // the panel in its compact column-major copy (leading dimension ldg: >= k rows)
-            const long long ldp = ldg;
+        // ---- LU of G with the forward substitution of X riding along.
+        // Panels are 64 columns wide, but the rank-64 updates they would feed the trailing matrix
+        // read and write every element of it (and of X) per 64 columns: two panels a, b are
+        // factorised before the trailing matrix sees either -- b needs a's update on its own 64
+        // columns (one skinny GEMM) and the row block of b right of it (another) -- and then one
+        // rank-128 update does the work of two: half the passes over the trailing matrix.
+        const long long ldp = ldg; // the panel's compact column-major copy: >= k rows per column
+        auto factor_panel = [&](int j0, int nbw) -> double * {
             hipLaunchKernelGGL((k_ref_panel_copy<false>), dim3((k - j0 + NB - 1) / NB), dim3(256), 0, st, k,
                                j0, nbw, G, ldg, Pn, ldp);
             // sub-panels: 8 columns while the active rows fit 4 per thread, 4 columns up to 8 rows
@@ -866,34 +1034,71 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, d
             }
             hipLaunchKernelGGL((k_ref_panel_copy<true>), dim3((k - j0 + NB - 1) / NB), dim3(256), 0, st, k,
                                j0, nbw, G, ldg, Pn, ldp);
-            hipLaunchKernelGGL(k_ref_swap, dim3((k + j0 + 255) / 256), dim3(256), 0, st, k, j0, nbw, G,
-                               X, ldg, piv);
-            auto trsm_l = nbw == NB ? k_ref_trsm_l<true> : k_ref_trsm_l<false>;
-            if (rest > 0) // U12 = L11^-1 A12
-                hipLaunchKernelGGL(trsm_l, dim3((rest + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, G,
-                                   ldg, j0 + nbw, k);
-            // forward substitution block of X: unit lower triangular in pivot order of its columns
-            // (k_ref_swap), so only the columns [0, j0 + nbw) hold anything
-            hipLaunchKernelGGL(trsm_l, dim3((j0 + nbw + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, X,
-                               ldg, 0, j0 + nbw);
+            // full panels: the inverses of L11 and U11 are formed beside the swaps (two more
+            // workgroups) and applied as products; a narrower last panel substitutes
+            double *tri = nbw == NB ? Tri + (long long)(j0 / NB) * 2 * NB * NB : nullptr;
+            hipLaunchKernelGGL(k_ref_swap, dim3((k + j0 + 255) / 256 + (tri ? 2 : 0)), dim3(256), 0, st, k,
+                               j0, nbw, G, X, ldg, piv, tri);
+            return tri;
+        };
+        // T[j0 .. j0 + nbw, cbeg .. cend) <- L11^-1 T[...]
+        auto solve_l = [&](int j0, int nbw, const double *tri, double *T, int cbeg, int cend) {
+            if (cend <= cbeg) return;
+            if (tri)
+                hipLaunchKernelGGL(k_ref_tri_apply, dim3((cend - cbeg + 63) / 64), dim3(256), 0, st, tri, T,
+                                   ldg, j0, cbeg, cend);
+            else
+                hipLaunchKernelGGL(k_ref_trsm_l<false>, dim3((cend - cbeg + 63) / 64), dim3(64), 0, st, j0,
+                                   nbw, G, ldg, T, ldg, cbeg, cend);
+        };
+        auto at = [&](double *M, int r, int c) { return M + (long long)r * ldg + c; };
+        for (int g0 = 0; g0 < k; g0 += 2 * NB) {
+            const int gw = (k - g0) < 2 * NB ? (k - g0) : 2 * NB;
+            const int na = gw < NB ? gw : NB, nb = gw - na; // panels a = [g0, ja), b = [ja, g0 + gw)
+            const int ja = g0 + na, je = g0 + gw;
+            const double *tri_a = factor_panel(g0, na);
+            solve_l(g0, na, tri_a, G, ja, k); // U12 of a, all columns right of it
+            // X stays unit lower triangular in pivot order of its columns (k_ref_swap): the row
+            // block of a panel holds something in the columns up to its own diagonal block only
+            solve_l(g0, na, tri_a, X, 0, ja);
+            if (nb > 0) {
+                // b's columns, rows below a:  -= L21a U12a
+                gemm_sub(k - ja, nb, na, at(G, ja, g0), ldg, at(G, g0, ja), ldg, at(G, ja, ja), ldg, st);
+                const double *tri_b = factor_panel(ja, nb);
+                // b's row block right of the pair, and in X:  -= L(b,a) (a's row block)
+                gemm_sub(nb, k - je, na, at(G, ja, g0), ldg, at(G, g0, je), ldg, at(G, ja, je), ldg, st);
+                gemm_sub(nb, ja, na, at(G, ja, g0), ldg, at(X, g0, 0), ldg, at(X, ja, 0), ldg, st);
+                solve_l(ja, nb, tri_b, G, je, k);
+                solve_l(ja, nb, tri_b, X, 0, je);
+            }
+            const int rest = k - je;
             if (rest > 0) {
-                const double *L21 = G + (long long)(j0 + nbw) * ldg + j0;
-                // A22 -= L21 * U12
-                gemm_sub(rest, rest, nbw, L21, ldg, G + (long long)j0 * ldg + j0 + nbw, ldg,
-                         G + (long long)(j0 + nbw) * ldg + j0 + nbw, ldg, st);
-                // X2 -= L21 * X1 (columns [0, j0 + nbw))
-                gemm_sub(rest, j0 + nbw, nbw, L21, ldg, X + (long long)j0 * ldg, ldg,
-                         X + (long long)(j0 + nbw) * ldg, ldg, st);
+                // A22 -= [L21a L21b] [U12a; U12b],  X2 -= [L21a L21b] [X1a; X1b] (columns [0, je))
+                gemm_sub(rest, rest, gw, at(G, je, g0), ldg, at(G, g0, je), ldg, at(G, je, je), ldg, st);
+                gemm_sub(rest, je, gw, at(G, je, g0), ldg, at(X, g0, 0), ldg, at(X, je, 0), ldg, st);
             }
         }
-        // ---- backward substitution with U
-        const int last = ((k - 1) / NB) * NB;
-        for (int j0 = last; j0 >= 0; j0 -= NB) {
-            const int nbw = (k - j0) < NB ? (k - j0) : NB;
-            auto trsm_u = nbw == NB ? k_ref_trsm_u<true> : k_ref_trsm_u<false>;
-            hipLaunchKernelGGL(trsm_u, dim3((k + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg, X, ldg, k);
-            if (j0 > 0) // X[0..j0) -= U01 * X1
-                gemm_sub(j0, k, nbw, G + j0, ldg, X + (long long)j0 * ldg, ldg, X, ldg, st);
+        // ---- backward substitution with U, the same pairs from the last to the first
+        auto solve_u = [&](int j0, int nbw) {
+            if (nbw == NB)
+                hipLaunchKernelGGL(k_ref_tri_apply, dim3((k + 63) / 64), dim3(256), 0, st,
+                                   Tri + (long long)(j0 / NB) * 2 * NB * NB + NB * NB, X, ldg, j0, 0, k);
+            else
+                hipLaunchKernelGGL(k_ref_trsm_u<false>, dim3((k + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg,
+                                   X, ldg, k);
+        };
+        for (int g0 = ((k - 1) / (2 * NB)) * (2 * NB); g0 >= 0; g0 -= 2 * NB) {
+            const int gw = (k - g0) < 2 * NB ? (k - g0) : 2 * NB;
+            const int na = gw < NB ? gw : NB, nb = gw - na;
+            const int ja = g0 + na;
+            if (nb > 0) {
+                solve_u(ja, nb);
+                // X1a -= U(a,b) X1b
+                gemm_sub(na, k, nb, at(G, g0, ja), ldg, at(X, ja, 0), ldg, at(X, g0, 0), ldg, st);
+            }
+            solve_u(g0, na);
+            if (g0 > 0) // X[0..g0) -= U[0..g0, pair] * X1
+                gemm_sub(g0, k, gw, at(G, 0, g0), ldg, at(X, g0, 0), ldg, X, ldg, st);
         }
         // ---- the columns of X back from pivot order: G^-1 = U^-1 L^-1 P.  G's factors are done
         // with: the permuted inverse goes there and X becomes the free panel

@@ -30,7 +30,11 @@ for k in ks:
             t0 = time.perf_counter()
             s.refactor()
             times.append(time.perf_counter() - t0)
+        # the fresh inverse at work: 64 pivots on it, and the health monitor's figure for them (the
+        # pivot element by FTRAN against the same element by BTRAN + pricing)
+        st = s.run(64)
         r = s.result(log=False)
+        check = f"{r.iterations} pivots on the fresh inverse: {st}, max_pivot_error {r.max_pivot_error:.1e}"
     dt = min(times)
     lu = (2.0 / 3.0) * k ** 3           # LU of G
     inv = (4.0 / 3.0) * k ** 3          # forward + backward substitution of the identity
@@ -38,4 +42,4 @@ for k in ks:
     print(f"m={m} k={k}: refactor {dt * 1e3:8.1f} ms (3 runs: {[round(t * 1e3, 1) for t in times]}), "
           f"{(lu + inv + rows) / dt / 1e12:6.2f} TFLOP/s over {(lu + inv + rows) / 1e9:.0f} GFLOP "
           f"(LU {lu / 1e9:.0f} + inverse {inv / 1e9:.0f} + slack rows {rows / 1e9:.0f}); "
-          f"status {r.status}, refactors {r.refactors}, create {t_create:.2f} s", flush=True)
+          f"refactors {r.refactors}, create {t_create:.2f} s; {check}", flush=True)
