@@ -7,14 +7,18 @@
 // nonbasic) only the k x k block G = A[R, S] needs factorising:
 //
 //   1. gather G (row a = dense row drow[a], column b = b-th structural basic position)
-//   2. blocked right-looking LU with partial pivoting, panel width NB = 64, the panel itself in
-//      sub-panels of 8 columns (pivot search = first maximum of |.|, swap, scale, rank-1 inside
-//      the sub-panel by one workgroup; rank-8 update of the rest of the panel by the whole chip)
-//        ->  row swaps outside the panel  ->  U12 = L11^-1 A12  ->
-//        trailing update A22 -= L21 * U12 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
-//   3. X = G^-1 by blocked forward / backward substitution on the identity, every off-diagonal
-//      block product again an MFMA GEMM.  The forward half keeps X unit lower triangular (columns in
-//      pivot order, put back by one permutation at the end): k^3 / 3 flops instead of k^3
+//   2. blocked right-looking LU with partial pivoting, panel width NB = 64, panels in PAIRS: the
+//      panel itself in sub-panels of 4-8 columns on a compact column-major copy (pivot search =
+//      first maximum of |.|, swap, scale, rank-1 inside the sub-panel by one workgroup with the
+//      rows in registers; rank-8 update of the rest of the panel by the whole chip)
+//        ->  row swaps outside the panel, the 64 x 64 diagonal blocks L11, U11 inverted beside them
+//        ->  U12 = L11^-1 A12 as a product  ->  after two panels:
+//        trailing update A22 -= [L21a L21b] [U12a; U12b] (rank 128) on the fp64 matrix cores
+//        (v_mfma_f64_16x16x4_f64)
+//   3. X = G^-1 by blocked forward / backward substitution on the identity, every block product an
+//      MFMA GEMM, the diagonal blocks by their inverses.  The forward half keeps X unit lower
+//      triangular (columns in pivot order, put back by one permutation at the end): k^3 / 3 flops
+//      instead of k^3
 //   4. Binv0[p_b, :] = X[b, :] for structural positions, Binv0[p', :] = -A[r', S] * X for the
 //      position of the basic slack of row r' (one more MFMA GEMM), eta file emptied.
 //
@@ -754,83 +758,50 @@ __global__ __launch_bounds__(256) void k_ref_swap(int k, int j0, int nbw, double
     }
 }
 
-// T[j0..j0+nbw, cbeg..cend) <- L11^-1 T[...]  (unit lower L11 = G[j0.., j0..]); thread per column
-template <bool FULL>
+// The substitutions of a NARROW last panel (fewer than 64 columns; full panels go through
+// k_ref_tri_apply): T[j0..j0+nbw, cbeg..cend) <- L11^-1 T[...]  (unit lower L11 = G[j0.., j0..]);
+// thread per column
 __global__ __launch_bounds__(256) void k_ref_trsm_l(int j0, int nbw, const double *__restrict__ G,
                                                     long long ldg, double *__restrict__ T,
                                                     long long ldt, int cbeg, int cend)
 {
-    // s_lt[j][i] = L[i][j]: the multipliers of elimination step j are contiguous (16-byte reads)
-    __shared__ __attribute__((aligned(16))) double s_lt[NB][NB];
+    // s_lt[j][i] = L[i][j]
+    __shared__ double s_lt[NB][NB];
     for (int e = threadIdx.x; e < nbw * nbw; e += blockDim.x)
         s_lt[e % nbw][e / nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
     __syncthreads();
     const int c = cbeg + blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cend) return;
-    double y[NB]; // FULL: every index below is a compile-time constant, y lives in registers
-    if (FULL) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
-        // column by column (right-looking): once y[j] is final, the NB - 1 - j rows below take their
-        // term of it -- independent FMAs, where the row-by-row form is one chain of dependent FMAs
-        // per row with an LDS read in front of each (50 us per launch, one wave per CU).  Every
-        // y[i] still collects its terms in ascending j: the same bits.
-#pragma unroll
-        for (int j = 0; j < NB - 1; ++j) {
-            const double yj = y[j];
-#pragma unroll
-            for (int i = j + 1; i < NB; ++i) y[i] = fma(-s_lt[j][i], yj, y[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
-    } else {
-        for (int i = 0; i < nbw; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
-        for (int i = 1; i < nbw; ++i) {
-            double acc = y[i];
-            for (int j = 0; j < i; ++j) acc = fma(-s_lt[j][i], y[j], acc);
-            y[i] = acc;
-        }
-        for (int i = 0; i < nbw; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
+    double y[NB];
+    for (int i = 0; i < nbw; ++i) y[i] = T[(long long)(j0 + i) * ldt + c];
+    for (int i = 1; i < nbw; ++i) {
+        double acc = y[i];
+        for (int j = 0; j < i; ++j) acc = fma(-s_lt[j][i], y[j], acc);
+        y[i] = acc;
     }
+    for (int i = 0; i < nbw; ++i) T[(long long)(j0 + i) * ldt + c] = y[i];
 }
 
 // X[j0..j0+nbw, :) <- U11^-1 X[...]  (upper U11 with diagonal); thread per column
-template <bool FULL>
 __global__ __launch_bounds__(256) void k_ref_trsm_u(int j0, int nbw, const double *__restrict__ G,
                                                     long long ldg, double *__restrict__ X,
                                                     long long ldx, int ncols)
 {
-    // s_ut[j][i] = U[i][j]: column j of U11 contiguous
-    __shared__ __attribute__((aligned(16))) double s_ut[NB][NB];
+    // s_ut[j][i] = U[i][j]
+    __shared__ double s_ut[NB][NB];
     for (int e = threadIdx.x; e < nbw * nbw; e += blockDim.x)
         s_ut[e % nbw][e / nbw] = G[(long long)(j0 + e / nbw) * ldg + j0 + e % nbw];
     __syncthreads();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
     double y[NB];
-    if (FULL) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
-        // column by column from the last (see k_ref_trsm_l): y[j] final, then its term leaves
-        // the j rows above -- independent FMAs
-#pragma unroll
-        for (int j = NB - 1; j >= 0; --j) {
-            const double yj = y[j] / s_ut[j][j];
-            y[j] = yj;
-#pragma unroll
-            for (int i = 0; i < j; ++i) y[i] = fma(-s_ut[j][i], yj, y[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
-    } else {
-        for (int i = 0; i < nbw; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
-        for (int j = nbw - 1; j >= 0; --j) {
-            const double yj = y[j] / s_ut[j][j];
-            y[j] = yj;
-            for (int i = 0; i < j; ++i) y[i] = fma(-s_ut[j][i], yj, y[i]);
-        }
-        for (int i = 0; i < nbw; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
+    for (int i = 0; i < nbw; ++i) y[i] = X[(long long)(j0 + i) * ldx + c];
+    for (int j = nbw - 1; j >= 0; --j) {
+        const double yj = y[j] / s_ut[j][j];
+        y[j] = yj;
+        for (int i = 0; i < j; ++i) y[i] = fma(-s_ut[j][i], yj, y[i]);
     }
+    for (int i = 0; i < nbw; ++i) X[(long long)(j0 + i) * ldx + c] = y[i];
 }
 
 // T[row0 .. row0 + 64, cbeg .. cend) <- Minv * T[...] in place, Minv a 64 x 64 block inverse
@@ -974,9 +945,10 @@ static void gemm_sub(int M, int N, int K, const double *A, long long lda, const 
                      long long ldb, double *C, long long ldc, hipStream_t st)
 {
     if (M <= 0 || N <= 0 || K <= 0) return;
-    // large shapes: B through LDS (k_ref_gemm_lds); a grid that does not fill the chip twice over
-    // keeps every wave on its own (no workgroup barrier)
-    if ((long long)((M + 63) / 64) * ((N + 63) / 64) >= 512 && !std::getenv("DZG_REF_GEMM_STRIPS")) {
+    // B through LDS (k_ref_gemm_lds) at every shape: the skinny products of the panel pairs too (one
+    // trip for the B panel and four for A, where the strip kernel makes sixteen dependent ones);
+    // DZG_REF_GEMM_STRIPS keeps the strip kernel for comparison
+    if (!std::getenv("DZG_REF_GEMM_STRIPS")) {
         hipLaunchKernelGGL((k_ref_gemm_lds<false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, M,
                            N, K, A, lda, B, ldb, C, ldc, (const int *)nullptr);
         return;
@@ -1048,7 +1020,7 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, d
                 hipLaunchKernelGGL(k_ref_tri_apply, dim3((cend - cbeg + 63) / 64), dim3(256), 0, st, tri, T,
                                    ldg, j0, cbeg, cend);
             else
-                hipLaunchKernelGGL(k_ref_trsm_l<false>, dim3((cend - cbeg + 63) / 64), dim3(64), 0, st, j0,
+                hipLaunchKernelGGL(k_ref_trsm_l, dim3((cend - cbeg + 63) / 64), dim3(64), 0, st, j0,
                                    nbw, G, ldg, T, ldg, cbeg, cend);
         };
         auto at = [&](double *M, int r, int c) { return M + (long long)r * ldg + c; };
@@ -1084,7 +1056,7 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, d
                 hipLaunchKernelGGL(k_ref_tri_apply, dim3((k + 63) / 64), dim3(256), 0, st,
                                    Tri + (long long)(j0 / NB) * 2 * NB * NB + NB * NB, X, ldg, j0, 0, k);
             else
-                hipLaunchKernelGGL(k_ref_trsm_u<false>, dim3((k + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg,
+                hipLaunchKernelGGL(k_ref_trsm_u, dim3((k + 63) / 64), dim3(64), 0, st, j0, nbw, G, ldg,
                                    X, ldg, k);
         };
         for (int g0 = ((k - 1) / (2 * NB)) * (2 * NB); g0 >= 0; g0 -= 2 * NB) {
@@ -1139,7 +1111,7 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, d
                 hipLaunchKernelGGL(k_ref_gather_slack, dim3((k + 255) / 256, nl), dim3(256), 0, st, k,
                                    d.A, d.lda, d.col0, lrow, scode, Wk, ldg);
             }
-            if ((long long)((nl + 63) / 64) * ((k + 63) / 64) >= 512 && !std::getenv("DZG_REF_GEMM_STRIPS"))
+            if (!std::getenv("DZG_REF_GEMM_STRIPS"))
                 hipLaunchKernelGGL((k_ref_gemm_lds<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
                                    nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
             else
