@@ -117,6 +117,25 @@ def test_first_pivots_are_the_cpu_oracles(core, lp_data):
     assert fast.near_ties == 0
 
 
+@pytest.mark.parametrize("k", [5000, 8192])
+def test_refactorisation_of_the_headline_basis_sizes(core, lp_data, k):
+    """Config 3 is named after its on-device LU refactor: a basis of 8192 rows with k structural
+    columns (k = 8192: the whole basis is dense; 5000: what the solve reaches) is factorised -- every
+    sub-panel regime (8 rows per thread, then 4), panel pairs, rank-128 MFMA updates, the slack-row
+    product -- and the fresh inverse must compute the pivot element of 48 pivots the same way twice
+    (FTRAN vs BTRAN + pricing, see tests/test_gpu_parity.py::test_refactorisation_at_every_panel_shape)."""
+    a, b, c = lp_data
+    basis = np.concatenate([np.arange(k), NS + np.arange(k, M)]).astype(np.int64)
+    nonbasis = np.concatenate([np.arange(k, NS), NS + np.arange(k)]).astype(np.int64)
+    lp = core.CoreLP(a=np.asarray(a), c=np.concatenate([c, np.zeros(M)]), basis=basis, nonbasis=nonbasis,
+                     x=np.ones(M), z=-np.ones(NS))
+    with core.Solver(lp, numerics=core.FAST, refactor_interval=-1, poll_interval=16) as s:
+        status = s.run(48)
+        r = s.result(log=False)
+    assert status == "iter_limit" and r.iterations == 48 and r.refactors == 1
+    assert r.max_pivot_error < 1e-8, r.max_pivot_error
+
+
 def test_first_pivots_of_4096_rows_are_the_cpu_oracles(core):
     """The same at 4096 x 8192 (seed 1006, the LP whose whole solve is certified by LAPACK below):
     40 pivots of the literal restatement (~45 s of one core each)."""

@@ -394,6 +394,35 @@ def test_fast_refactor_keeps_pivot_sequence(core, seed, m, ns, interval):
     assert got.max_pivot_error < 1e-9
 
 
+@pytest.mark.parametrize("m,k", [(700, 1), (700, 63), (700, 64), (700, 65), (700, 127), (700, 128),
+                                 (700, 129), (700, 200), (700, 449), (700, 700), (2100, 1100),
+                                 (2100, 2100)])
+def test_refactorisation_at_every_panel_shape(core, m, k):
+    """The factorisation of a basis with exactly k structural columns -- one narrow panel, full
+    panels, a pair with a narrow second panel, pairs followed by a single panel (k_refactor.hip) --
+    checked on what it is for: 48 pivots on the fresh inverse with the pivot element computed
+    twice, by FTRAN (rows of the inverse times the entering column) and by BTRAN + pricing (row p of
+    the inverse against the matrix); they agree to rounding only if the inverse is the inverse.
+    x and z are arbitrary (x > 0 > z: the method has work to do); the refactorisation does not
+    look at them."""
+    ns = 2 * m
+    a, b, c = core.gen_dense_lp(seed=300 + k, m=m, n_struct=ns)
+    basis = np.concatenate([np.arange(k), ns + np.arange(k, m)]).astype(np.int64)
+    nonbasis = np.concatenate([np.arange(k, ns), ns + np.arange(k)]).astype(np.int64)
+    lp = core.CoreLP(a=np.asarray(a), c=np.concatenate([c, np.zeros(m)]), basis=basis, nonbasis=nonbasis,
+                     x=np.ones(m), z=-np.ones(ns))
+    with core.Solver(lp, numerics=core.FAST, refactor_interval=-1, poll_interval=16) as s:
+        status = s.run(48)
+        r = s.result(log=False)
+        assert status == "iter_limit" and r.iterations == 48 and r.refactors == 1
+        assert r.max_pivot_error < 1e-9, r.max_pivot_error
+        s.refactor()  # and again on the basis 48 pivots later (k has moved by a few)
+        status = s.run(48)
+        r = s.result(log=False)
+    assert status == "iter_limit" and r.iterations == 96 and r.refactors == 2
+    assert r.max_pivot_error < 1e-9, r.max_pivot_error
+
+
 def test_fast_refactor_on_demand_large(core):
     """Refactor in the middle of a larger solve (k in the hundreds, several LU panels) and
     finish: the optimum must still match the independent HiGHS value."""

@@ -21,7 +21,7 @@ for k in ks:
     basis = np.concatenate([np.arange(k), ns + np.arange(k, m)]).astype(np.int64)
     nonbasis = np.concatenate([np.arange(k, ns), ns + np.arange(k)]).astype(np.int64)
     lp = core.CoreLP(a=np.asarray(a), c=cc, basis=basis, nonbasis=nonbasis, x=np.ones(m),
-                     z=np.ones(ns))
+                     z=-np.ones(ns))  # (x > 0 > z: pivots to make on the fresh inverse)
     t0 = time.perf_counter()
     with core.Solver(lp, numerics=core.FAST, refactor_interval=-1) as s:
         t_create = time.perf_counter() - t0   # upload + the initial refactorisation
