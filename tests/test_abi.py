@@ -290,3 +290,30 @@ def test_reference_package_name_resolves_to_this_implementation():
                                     "exceptions"}
     for name in ("Variable", "PyLinExpr", "PyAffExpr", "PyInequality", "PySolution", "solve"):
         assert hasattr(dantzig.rust, name)          # src/lib.rs:29-38
+
+
+def test_resumed_from_takes_a_result_or_an_archive_of_one():
+    """core.resumed_from (host only): the six state arrays -- from a CoreResult-like object or from a
+    mapping such as an .npz archive -- replace the LP's start; matrix and objective stay."""
+    import io
+    import types
+
+    from dantzig_amd import core
+
+    a = np.arange(6, dtype=np.float64).reshape(2, 3)
+    lp = core.CoreLP.from_inequality_form(a, np.array([1.0, 2.0]), np.array([1.0, 1.0, 1.0]))
+    assert lp.xbar is None and lp.zbar is None  # Simplex::new's ones are the library's default
+    state = dict(basis=np.array([0, 4]), nonbasis=np.array([1, 2, 3]), x=np.array([0.5, 0.25]),
+                 xbar=np.array([0.1, 1.0]), z=np.array([1.0, 2.0, 3.0]), zbar=np.array([1.0, 0.2, 1.0]))
+    for src in (types.SimpleNamespace(**state), state):
+        got = core.resumed_from(lp, src)
+        for name, want in state.items():
+            assert np.array_equal(getattr(got, name), want), name
+        assert got.a is lp.a and got.c is lp.c and got.m == 2 and got.n == 5
+        assert got.basis.dtype == np.int64 and got.xbar.dtype == np.float64
+    buf = io.BytesIO()
+    np.savez(buf, **state)
+    buf.seek(0)
+    got = core.resumed_from(lp, np.load(buf))
+    assert np.array_equal(got.zbar, state["zbar"]) and np.array_equal(got.basis, state["basis"])
+    assert lp.xbar is None  # the original LP is untouched
