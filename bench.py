@@ -294,7 +294,10 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
              "tree": core.PRICE_TREE}[price_name]
     numerics = core.FAST if numerics_name == "fast" else core.STRICT
-    kernel = ("k_price_csc_tree" if numerics_name == "fast" and price_name != "seq"
+    # (one GPU, FAST: the sparse-basis path prices over the live entries of a column only;
+    # DZG_SP_PRICE_FULL=1 brings the full pass back for comparison)
+    kernel = (("k_price_csc_tree" if os.environ.get("DZG_SP_PRICE_FULL") == "1" else "k_price_csc_rl")
+              if numerics_name == "fast" and price_name != "seq"
               else "k_price_csc") if sparse_per_col > 0 else (
         "k_price_seq2" if numerics_name == "strict" else PRICE_KERNELS[price_name])
     t_up = time.perf_counter()

@@ -37,7 +37,7 @@ EXPORTS = [
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
     "dzg_gen_dense_lp_block", "dzg_solver_set_profile", "dzg_kernel_neg_t_dot_csc",
     "dzg_shard_comm_size", "dzg_solver_upload_columns", "dzg_debug_hold_cus", "dzg_debug_hold_wait",
-    "dzg_core_solve_full_csc",
+    "dzg_core_solve_full_csc", "dzg_debug_live_lists",
 ]
 
 
@@ -164,6 +164,8 @@ def lib() -> C.CDLL:
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p]
         _lib.dzg_debug_hold_cus.argtypes = [C.c_int32, C.c_int32, C.c_double]
+        _lib.dzg_debug_live_lists.restype = C.c_int64
+        _lib.dzg_debug_live_lists.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dzg_solver_upload_columns.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                                    C.c_int64]
     return _lib

@@ -349,6 +349,12 @@ struct DzgDev {
     double *bval;          // [nnz] ... and values
     double *dxs;           // [m]  dx on the structural positions, by row of X
     int *acol_code;        // column code currently scattered in acol (INT_MIN: none)
+    // live entries of every structural column (rows of R: the rows whose slack is nonbasic), in the
+    // column's CSC slice; NULL: not kept (price_kernel = SEQ, DZG_SP_PRICE_FULL=1)
+    int *lcnt;             // [ns]  live entries of column j ...
+    int *lrow;             // [nnz] ... their rows, at cptr[j] + i, in the order the rows joined R
+    double *lval;          // [nnz] ... and values
+    unsigned long long *rl_work; // [DZG_PRICE_CSC_BLOCKS] entries k_price_csc_rl walked, per workgroup
     // strict numerics
     DzgLu lu;
     double eps;
@@ -357,6 +363,11 @@ struct DzgDev {
     int repl;            // 1: every structural column is resident (A points at column col0 of the
                          //    whole matrix, so `A + (code - col0) * lda` reaches any column)
     long long xstride;   // exchange record stride in doubles (8: header only, repl)
+    int k_hint;          // an UPPER BOUND of ctl->ncompact while the enqueued batch runs (the host's
+                         // last reading + the batch: k grows by at most one per pivot); 0: unknown
+                         // (= m).  Sizes the eta flush's grid: k is only known on the device, and a
+                         // grid for k = m is 611 000 workgroups at 50 000 rows, all but (k / 64)^2
+                         // of them empty -- 600 us per flush, 9 us per pivot
     int price_cols_hint; // host's last reading of ctl->nb_struct (0: unknown): picks the pricing
                          // kernel's pass shape; any shape is correct for any count
 };
@@ -392,6 +403,7 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st);
 int dzg_price_partials(int kernel);
 int dzg_price_partials_dev(const DzgDev &d, int kernel);
 #define DZG_PRICE_CSC_KERNEL 100 // internal id: the CSC pricing kernel
+#define DZG_RL_WORK_SLOTS 2048   // workgroups of k_price_csc_rl (= its per-workgroup work counters)
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,
                           int ncols, const double *v, double *out, hipStream_t st);
 void dzg_launch_price_csc_raw(const long long *cptr, const int *ridx, const double *cval,

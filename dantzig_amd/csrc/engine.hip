@@ -15,6 +15,7 @@
 #include <limits>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -428,6 +429,16 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             TRY(dev_alloc(s, &d.bcnt, (size_t)(m ? m : 1)));
             TRY(dev_alloc(s, &d.bcol, ci.size() + 1));
             TRY(dev_alloc(s, &d.bval, rv.size() + 1));
+            // live-entry lists of the columns (k_price_csc_rl); the reference-order kernel and the
+            // A/B switch DZG_SP_PRICE_FULL=1 price over every stored entry instead
+            const char *full = std::getenv("DZG_SP_PRICE_FULL");
+            if (o.price_kernel != DZG_PRICE_SEQ && !(full && full[0] == '1')) {
+                TRY(dev_alloc(s, &d.lcnt, (size_t)(ns ? ns : 1)));
+                TRY(dev_alloc(s, &d.lrow, ri.size() + 1));
+                TRY(dev_alloc(s, &d.lval, cv.size() + 1));
+                TRY(dev_alloc(s, &d.rl_work, (size_t)DZG_RL_WORK_SLOTS));
+                HIP_OK(hipMemsetAsync(d.rl_work, 0, sizeof(unsigned long long) * DZG_RL_WORK_SLOTS, s->st));
+            }
         }
     }
     // --- constraint matrix: column-major, zero-padded to lda rows (16-B aligned columns)
@@ -973,8 +984,14 @@ static int run_fast(dzg_solver *s)
         const int batch = batch_size(s);
         s->since_flush = s->h_ctl->neta; // pending etas as the device counts them
         s->d.price_cols_hint = (int)s->h_ctl->nb_struct + batch; // (at most one more per pivot)
+        // the eta flush's grid follows k as the host knows it (k grows by at most one per pivot).
+        // Only around launches this loop enqueues itself: the phase entry points are also driven
+        // from outside (sharded hosts), where nobody refreshes the bound
+        const int k_bound = (int)s->h_ctl->ncompact + batch;
         if (s->d.spb) {
+            s->d.k_hint = k_bound;
             for (int b = 0; b < batch; ++b) enqueue_sparse_iteration(s, b);
+            s->d.k_hint = 0;
         } else if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
             TRY(shard_buffers(s));
             const size_t nb = sizeof(double) * (size_t)s->d.xstride;
@@ -992,10 +1009,12 @@ static int run_fast(dzg_solver *s)
             // (k grows by at most one per pivot) the batch runs as seven launches
             s->batch_chain = s->chain_bar && s->h_ctl->iter >= s->chain_retry_iter &&
                              (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
+            s->d.k_hint = k_bound;
             if (s->batch_chain)
                 for (int b = 0; b < batch; ++b) enqueue_chain_iteration(s, b);
             else
                 for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
+            s->d.k_hint = 0;
         }
         s->since_refactor += batch;
         TRY(read_ctl(s));
@@ -1390,6 +1409,54 @@ extern "C" int dzg_solver_run(dzg_solver *s, int64_t max_new_iters)
     return s->h_ctl->status;
 }
 
+// Test hook: the live-entry lists of a sparse-basis solver (k_price_csc_rl's input) against their
+// definition -- column j lists exactly its stored entries whose row has a nonbasic slack
+// (dslot >= 0), each once, with the stored value.
+extern "C" int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries)
+{
+    if (!s) return fail(DZG_E_ARG, "NULL argument");
+    const DzgDev &d = s->d;
+    if (!d.spb || !d.lcnt) return fail(DZG_E_ARG, "this solver keeps no live-entry lists");
+    HIP_OK(hipSetDevice(s->opts.device));
+    HIP_OK(hipStreamSynchronize(s->st));
+    const size_t ns = (size_t)d.ns, m = (size_t)d.m;
+    std::vector<long long> cp(ns + 1);
+    std::vector<int> dslot(m), lcnt(ns);
+    HIP_OK(hipMemcpy(cp.data(), d.cptr, sizeof(long long) * (ns + 1), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(dslot.data(), d.dslot, sizeof(int) * m, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(lcnt.data(), d.lcnt, sizeof(int) * ns, hipMemcpyDeviceToHost));
+    const size_t nnz = (size_t)cp[ns];
+    std::vector<int> ri(nnz + 1), lrow(nnz + 1);
+    std::vector<double> cv(nnz + 1), lval(nnz + 1);
+    if (nnz) {
+        HIP_OK(hipMemcpy(ri.data(), d.ridx, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(cv.data(), d.cval, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(lrow.data(), d.lrow, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(lval.data(), d.lval, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+    }
+    int64_t bad = 0, total = 0;
+    std::vector<std::pair<int, double>> want, got;
+    for (size_t j = 0; j < ns; ++j) {
+        want.clear();
+        got.clear();
+        for (long long e = cp[j]; e < cp[j + 1]; ++e)
+            if (dslot[(size_t)ri[(size_t)e]] >= 0) want.emplace_back(ri[(size_t)e], cv[(size_t)e]);
+        const long long span = cp[j + 1] - cp[j];
+        if (lcnt[j] < 0 || lcnt[j] > span) {
+            ++bad;
+            continue;
+        }
+        for (int i = 0; i < lcnt[j]; ++i)
+            got.emplace_back(lrow[(size_t)cp[j] + (size_t)i], lval[(size_t)cp[j] + (size_t)i]);
+        std::sort(got.begin(), got.end());
+        std::sort(want.begin(), want.end());
+        if (got != want) ++bad;
+        total += lcnt[j];
+    }
+    if (entries) *entries = total;
+    return bad;
+}
+
 extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
 {
     if (!s || !res) return fail(DZG_E_ARG, "NULL argument");
@@ -1444,6 +1511,15 @@ extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
         res->kernel_launches[c] = s->kernel_launches[c];
     }
     res->price_bytes = s->h_ctl->price_bytes;
+    if (s->d.rl_work) { // live-entry pricing counts the entries it walked itself: 12 bytes each
+        std::vector<unsigned long long> w(DZG_RL_WORK_SLOTS);
+        HIP_OK(hipMemcpyAsync(w.data(), s->d.rl_work, sizeof(unsigned long long) * w.size(),
+                              hipMemcpyDeviceToHost, s->st));
+        HIP_OK(hipStreamSynchronize(s->st));
+        unsigned long long walked = 0;
+        for (unsigned long long x : w) walked += x;
+        res->price_bytes += 12.0 * (double)walked;
+    }
     res->solve_ms = s->solve_ms;
     res->max_pivot_error = s->max_err_life;
     res->near_ties = s->h_ctl->near_ties;

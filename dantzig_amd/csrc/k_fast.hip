@@ -697,7 +697,8 @@ void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
 
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
 {
-    const int kmax = d.m; // ncompact <= m; grids cover the worst case, kernels mask by ctl
+    // ncompact <= k_hint <= m (the host's bound for the batch in flight); the kernels mask by ctl
+    const int kmax = d.k_hint > 0 && d.k_hint < d.m ? d.k_hint : d.m;
     hipLaunchKernelGGL(k_fast_gather_w, dim3((kmax + 15 + 255) / 256, R_), dim3(256), 0, st, d.ctl,
                        d.W, d.ldw, d.drow, d.Wc);
     static const bool steps = std::getenv("DZG_FLUSH_STEPS") != nullptr; // (A/B switch, tools)

@@ -1,6 +1,8 @@
 // k_price.hip -- launchers of the pricing kernels (kernels and design notes: k_price_kernels.h)
 #include "k_price_kernels.h"
 
+static_assert(DZG_RL_WORK_SLOTS == DZG_PRICE_CSC_BLOCKS, "work counters of k_price_csc_rl");
+
 static int resolve(int kernel)
 {
     return kernel == DZG_PRICE_WAVE || kernel == DZG_PRICE_TREE ? kernel : DZG_PRICE_SEQ;
@@ -116,6 +118,13 @@ void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
 {
     if (d.csc) {
+        if (d.spb && d.lcnt && kernel != DZG_PRICE_SEQ) { // sparse basis: the live entries only
+            if (d.q > 0)
+                hipLaunchKernelGGL(k_price_csc_rl, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl,
+                                   d.cptr, d.lcnt, d.lrow, d.lval, d.q, d.plist, d.pcode, d.nbcode, d.v,
+                                   d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, d.rl_work);
+            return;
+        }
         launch_csc(d, d.plist, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, kernel == DZG_PRICE_SEQ, st);
         return;
     }

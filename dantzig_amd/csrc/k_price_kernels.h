@@ -714,6 +714,115 @@ __global__ __launch_bounds__(256) void k_price_csc_tree(
     price_publish(best, rz_r, rz_k, rz_h);
 }
 
+// ---------------------------------------------------------------------------------
+// k_price_csc_rl: FAST pricing of the sparse-basis path (k_sparse.hip) over the LIVE entries only.
+// v = row p of B^-1 in row coordinates is zero outside R (the k rows whose slack is nonbasic) and
+// the leaving slack's own row, so a column's sum only needs its entries in those rows.  Every
+// column keeps them as a list in its own CSC slice (lcnt / lrow / lval: k_sp_btran appends the row
+// that is about to join R before this launch, k_sp_pivot removes the row that left), and the pass
+// walks nnz * k / m entries instead of nnz: 1 in 50 at k = 1 000 of config 4, where the full pass
+// (k_price_csc_tree) spent 35 of a pivot's 100 us gathering zeros of v.  Same lane layout as the
+// tree kernel (8 lanes per column, two chains per lane, xor tree); the order inside a list is the
+// order its rows joined R, a function of the pivot sequence alone (deterministic); it is not the
+// reference's order (STRICT and price_kernel = SEQ use k_price_csc).
+// work[blockIdx.x] accumulates the entries this workgroup walked (roofline accounting, exact).
+// ---------------------------------------------------------------------------------
+#define RL_LPC 4 // lanes per column: 2048 x 256 / 4 = 131 072 columns in one pass
+__global__ __launch_bounds__(256) void k_price_csc_rl(
+    const DzgCtl *ctl, const long long *__restrict__ cptr, const int *__restrict__ lcnt,
+    const int *__restrict__ lrow, const double *__restrict__ lval, int q,
+    const int *__restrict__ plist, const int *__restrict__ pcode, const int *__restrict__ nbcode,
+    const double *__restrict__ v, double *__restrict__ dz, const double *__restrict__ z,
+    const double *__restrict__ zbar, double *__restrict__ rz_r, int *__restrict__ rz_k,
+    double *__restrict__ rz_h, unsigned long long *__restrict__ work)
+{
+    __shared__ unsigned int s_work[4];
+    // first trip, side by side: the control block, this thread's unit-column position and the
+    // first column of its lane group (plist / pcode hold q entries; those beyond nb_struct are
+    // stale and only used once the count has arrived)
+    const int nthreads = gridDim.x * blockDim.x;
+    const int spos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = threadIdx.x & (RL_LPC - 1);
+    const int group = spos / RL_LPC;
+    const int ngroups = nthreads / RL_LPC;
+    int scode = 0, pos0 = -1, code0 = -1;
+    if (spos < q) scode = nbcode[spos];
+    if (group < q) {
+        pos0 = plist[group];
+        code0 = pcode[group];
+    }
+    const int status = ctl->status, count = (int)ctl->nb_struct;
+    const double mu = ctl->mu, tau = ctl->tau;
+    if (status != DZG_RUNNING) return;
+    DzgCand2 best = dzg_cand2_none();
+    double sv = 0.0, sz = 0.0, szb = 0.0;
+    if (scode < 0) { // second trip, beside the column's descriptors
+        sv = v[-1 - scode];
+        sz = z[spos];
+        szb = zbar[spos];
+    }
+    unsigned int walked = 0;
+    for (int idx0 = 0; idx0 < count; idx0 += ngroups) { // wave-uniform trip count
+        const int idx = idx0 + group;
+        int pos = -1, code = -1;
+        long long e0 = 0, e1 = 0;
+        if (idx < count) {
+            pos = idx0 == 0 ? pos0 : plist[idx];
+            code = idx0 == 0 ? code0 : pcode[idx];
+            if (code >= 0) {
+                e0 = cptr[code];
+                e1 = e0 + lcnt[code];
+            }
+        }
+        double zc = 0.0, zbc = 0.0;
+        if (code >= 0 && sub == 0) {
+            zc = z[pos];
+            zbc = zbar[pos];
+            walked += (unsigned int)(e1 - e0);
+        }
+        double a0 = 0.0, a1 = 0.0; // two independent chains per lane
+        long long e = e0 + sub;
+        for (; e + RL_LPC < e1; e += 2 * RL_LPC) {
+            const int r0 = lrow[e], r1 = lrow[e + RL_LPC];
+            const double c0 = lval[e], c1 = lval[e + RL_LPC];
+            a0 = fma(c0, v[r0], a0);
+            a1 = fma(c1, v[r1], a1);
+        }
+        if (e < e1) a0 = fma(lval[e], v[lrow[e]], a0);
+        double acc = a0 + a1;
+#pragma unroll
+        for (int off = RL_LPC / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);
+        if (code >= 0 && sub == 0) {
+            dz[pos] = -acc;
+            price_candidate_v(best, -acc, pos, mu, tau, zc, zbc);
+        }
+    }
+    // ---- unit columns (the arithmetic of price_slack_positions)
+    if (scode < 0) {
+        const double p = 1.0 * -sv;
+        const double d = 0.0 + p;
+        dz[spos] = d;
+        price_candidate_v(best, d, spos, mu, tau, sz, szb);
+    }
+    for (int pos = spos + nthreads; pos < q; pos += nthreads) { // more positions than threads
+        const int code = nbcode[pos];
+        if (code < 0) {
+            const double p = 1.0 * -v[-1 - code];
+            const double d = 0.0 + p;
+            dz[pos] = d;
+            price_candidate(best, d, pos, mu, tau, z, zbar);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) walked += __shfl_xor(walked, off, DZG_WAVE);
+    if ((threadIdx.x & 63) == 0) s_work[threadIdx.x >> 6] = walked;
+    price_publish(best, rz_r, rz_k, rz_h); // (its barriers order s_work)
+    if (threadIdx.x == 0) // (an atomic without return: no trip to wait for at the end of the launch)
+        __hip_atomic_fetch_add(work + blockIdx.x,
+                               (unsigned long long)s_work[0] + s_work[1] + s_work[2] + s_work[3],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define DZG_PRICE_CSC_BLOCKS 2048
 #define DZG_PRICE_SEQ_BLOCKS 256   // x 4 waves: one workgroup per CU
 #define DZG_PRICE_WAVE_BLOCKS 2048 // x 4 waves

@@ -82,6 +82,16 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
     __shared__ int s_slot[256];
     __shared__ double s_val[256];
     __shared__ double s_beta[R_];
+    __shared__ int s_wcnt[4];
+    // (the partial candidates are fetched beside the control block, not behind it: after a kernel
+    // boundary every first touch is a trip to memory, and these two need not queue)
+    DzgCand2 cj = dzg_cand2_none(), ci = dzg_cand2_none(), cw = dzg_cand2_none();
+    if (KIND == DZG_STEP_PRIMAL) {
+        cj = reduce_partials(fpz_r, fpz_k, fpz_h, SP_NB_UPD);
+        ci = reduce_partials(fpx_r, fpx_k, fpx_h, SP_NB_UPD);
+    } else {
+        cw = reduce_partials(rz_r, rz_k, rz_h, nrz);
+    }
     DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -90,15 +100,12 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
     int epos;
     double mu;
     if (KIND == DZG_STEP_PRIMAL) {
-        const DzgCand2 cj = reduce_partials(fpz_r, fpz_k, fpz_h, SP_NB_UPD);
-        const DzgCand2 ci = reduce_partials(fpx_r, fpx_k, fpx_h, SP_NB_UPD);
         int kind;
         if (!fast_status(ctl, c, lead, cj, ci, eps, m, false, kind, &mu)) return;
         if (kind != DZG_STEP_PRIMAL) return;
         epos = cj.k;
     } else {
         if (c.kind != DZG_STEP_DUAL) return; // (written by the primal launch of this iteration)
-        const DzgCand2 cw = reduce_partials(rz_r, rz_k, rz_h, nrz);
         if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_INFEASIBLE)) return;
         epos = cw.k;
         mu = c.mu;
@@ -127,55 +134,100 @@ __global__ __launch_bounds__(256) void k_sp_ftran_s(
         }
         if (threadIdx.x == 0) *acol_code = code;
     }
-    // ---- beta_t = W_t . a_R, thread t, over the column's entries in chunks of 256
-    double bacc = 0.0;
-    for (long long base = e0; base < e1; base += 256) {
-        __syncthreads();
+    // ---- beta_t = W_t . a_R, thread t, over the column's entries in chunks of 256.  A chunk is
+    // staged COMPACTED -- only the entries in rows of R (dslot >= 0), in their order -- so that the
+    // gathers below are loops without branches whose loads leave four at a time: a taken branch
+    // around every load made each entry of a_R a trip to memory of its own (1 at k = 1 000, 45
+    // deep in the solve of config 4).  The sums are the same sums in the same order.
+    auto stage = [&](long long base) -> int {
+        __syncthreads(); // the previous chunk has been consumed
         const long long e = base + threadIdx.x;
+        int slot = -1;
+        double val = 0.0;
         if (e < e1) {
             const int r = code >= 0 ? ridx[e] : -1 - code;
-            s_slot[threadIdx.x] = dslot[r];
-            s_val[threadIdx.x] = code >= 0 ? cval[e] : 1.0;
+            slot = dslot[r];
+            val = code >= 0 ? cval[e] : 1.0;
         }
+        const unsigned long long mask = __ballot(slot >= 0);
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) s_wcnt[wave] = __popcll(mask);
         __syncthreads();
-        const int cnt = (int)((e1 - base) < 256 ? (e1 - base) : 256);
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        if (slot >= 0) {
+            const int at = off + __popcll(mask & ((1ull << lane) - 1ull));
+            s_slot[at] = slot;
+            s_val[at] = val;
+        }
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+        return total;
+    };
+    double bacc = 0.0;
+    int cnt = 0;
+    for (long long base = e0; base < e1; base += 256) {
+        cnt = stage(base);
         if ((int)threadIdx.x < neta) {
             const double *wt = W + (long long)threadIdx.x * ldw;
-            for (int i = 0; i < cnt; ++i)
-                if (s_slot[i] >= 0) bacc = fma(wt[s_slot[i]], s_val[i], bacc);
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const double w0 = wt[s_slot[i]], w1 = wt[s_slot[i + 1]], w2 = wt[s_slot[i + 2]],
+                             w3 = wt[s_slot[i + 3]];
+                bacc = fma(w0, s_val[i], bacc);
+                bacc = fma(w1, s_val[i + 1], bacc);
+                bacc = fma(w2, s_val[i + 2], bacc);
+                bacc = fma(w3, s_val[i + 3], bacc);
+            }
+            for (; i < cnt; ++i) bacc = fma(wt[s_slot[i]], s_val[i], bacc);
         }
     }
     if (threadIdx.x < R_) s_beta[threadIdx.x] = (int)threadIdx.x < neta ? bacc : 0.0;
+    __syncthreads(); // (a column without stored entries runs none of the staging barriers)
     // ---- body (the last chunk of the column is still staged when there is only one)
     DzgCand2 best = dzg_cand2_none();
     const bool one_chunk = e1 - e0 <= 256;
     for (int b0 = blockIdx.x * blockDim.x; b0 < k; b0 += gridDim.x * blockDim.x) { // block-uniform
         const int b = b0 + threadIdx.x;
         const double *row = X + (long long)(b < k ? b : 0) * ldb;
+        // what does not depend on the staged column leaves first: the position, its x and xbar
+        const int i = b < k ? spos[b] : 0;
+        double xi = 0.0, xbi = 0.0;
+        if (KIND == DZG_STEP_PRIMAL && b < k) {
+            xi = x[i];
+            xbi = xbar[i];
+        }
         double acc = 0.0;
         for (long long base = e0; base < e1; base += 256) {
-            if (!one_chunk) {
-                __syncthreads();
-                const long long e = base + threadIdx.x;
-                if (e < e1) {
-                    const int r = code >= 0 ? ridx[e] : -1 - code;
-                    s_slot[threadIdx.x] = dslot[r];
-                    s_val[threadIdx.x] = code >= 0 ? cval[e] : 1.0;
+            if (!one_chunk) cnt = stage(base);
+            else __syncthreads(); // (orders s_beta before its first use)
+            if (b < k) {
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    const double r0 = row[s_slot[j]], r1 = row[s_slot[j + 1]], r2 = row[s_slot[j + 2]],
+                                 r3 = row[s_slot[j + 3]];
+                    acc = fma(r0, s_val[j], acc);
+                    acc = fma(r1, s_val[j + 1], acc);
+                    acc = fma(r2, s_val[j + 2], acc);
+                    acc = fma(r3, s_val[j + 3], acc);
                 }
+                for (; j < cnt; ++j) acc = fma(row[s_slot[j]], s_val[j], acc);
             }
-            __syncthreads(); // (also orders s_beta before its first use)
-            const int cnt = (int)((e1 - base) < 256 ? (e1 - base) : 256);
-            if (b < k)
-                for (int i = 0; i < cnt; ++i)
-                    if (s_slot[i] >= 0) acc = fma(row[s_slot[i]], s_val[i], acc);
         }
         if (b < k) {
-            for (int t = 0; t < neta; ++t) acc = fma(-U[(long long)t * ldu + b], s_beta[t], acc);
-            const int i = spos[b];
+            int t = 0;
+            for (; t + 8 <= neta; t += 8) { // (eight coalesced loads side by side, the sum in order)
+                double u[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) u[g] = U[(long long)(t + g) * ldu + b];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) acc = fma(-u[g], s_beta[t + g], acc);
+            }
+            for (; t < neta; ++t) acc = fma(-U[(long long)t * ldu + b], s_beta[t], acc);
             dxs[b] = acc;
             dx[i] = acc;
             if (KIND == DZG_STEP_PRIMAL) {
-                const double xi = x[i], scaled = mu * xbar[i];
+                const double scaled = mu * xbi;
                 const double den = xi + scaled;
                 DzgCand2 cnd;
                 cnd.r = dzg_div(acc, den);
@@ -213,20 +265,48 @@ __global__ __launch_bounds__(256) void k_sp_ftran_l(
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
     double *__restrict__ rx_r, int *__restrict__ rx_k, double *__restrict__ rx_h, int part0)
 {
+    // this thread's first row: what only depends on the row leaves beside the control block
+    const int r_first = blockIdx.x * blockDim.x + threadIdx.x;
+    int p_first = -1, n_first = 0;
+    double a_first = 0.0;
+    long long e_first = 0;
+    if (r_first < m) {
+        p_first = rowpos[r_first];
+        a_first = acol[r_first];
+        e_first = rptr[r_first];
+        n_first = bcnt[r_first];
+    }
     const DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING || c.kind != need_kind) return;
     const double mu = c.mu, tau = c.tau;
     DzgCand2 best = dzg_cand2_none();
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < m; r += gridDim.x * blockDim.x) {
-        const int p = rowpos[r]; // -1: the slack of row r is nonbasic (r in R)
+    for (int r = r_first; r < m; r += gridDim.x * blockDim.x) {
+        const bool first = r == r_first;
+        const int p = first ? p_first : rowpos[r]; // -1: the slack of row r is nonbasic (r in R)
         if (p < 0) continue;
-        double acc = acol[r];
-        const long long e0 = rptr[r];
-        const int n = bcnt[r];
-        for (int i = 0; i < n; ++i) acc = fma(-bval[e0 + i], dxs[bslot[bcol[e0 + i]]], acc);
+        double acc = first ? a_first : acol[r];
+        const long long e0 = first ? e_first : rptr[r];
+        const int n = first ? n_first : bcnt[r];
+        double xi = 0.0, xbi = 0.0;
+        if (need_kind == DZG_STEP_PRIMAL) {
+            xi = x[p];
+            xbi = xbar[p];
+        }
+        int i = 0;
+        for (; i + 4 <= n; i += 4) { // four entries' chains (column -> row of X -> dx_S) side by side
+            const int c0 = bcol[e0 + i], c1 = bcol[e0 + i + 1], c2 = bcol[e0 + i + 2], c3 = bcol[e0 + i + 3];
+            const double v0 = bval[e0 + i], v1 = bval[e0 + i + 1], v2 = bval[e0 + i + 2], v3 = bval[e0 + i + 3];
+            const int s0 = bslot[c0], s1 = bslot[c1], s2 = bslot[c2], s3 = bslot[c3];
+            const double d0 = dxs[s0], d1 = dxs[s1], d2 = dxs[s2], d3 = dxs[s3];
+            acc = fma(-v0, d0, acc);
+            acc = fma(-v1, d1, acc);
+            acc = fma(-v2, d2, acc);
+            acc = fma(-v3, d3, acc);
+        }
+        for (; i < n; ++i) acc = fma(-bval[e0 + i], dxs[bslot[bcol[e0 + i]]], acc);
         dx[p] = acc;
         if (need_kind == DZG_STEP_PRIMAL) {
-            const double xi = x[p], scaled = mu * xbar[p];
+            const double scaled = mu * xbi;
             const double den = xi + scaled;
             DzgCand2 cnd;
             cnd.r = dzg_div(acc, den);
@@ -265,18 +345,22 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
     const int *__restrict__ drow, const int *__restrict__ dslot,
     const double *__restrict__ rx_r, const int *__restrict__ rx_k,
-    const double *__restrict__ rx_h, double *__restrict__ v)
+    const double *__restrict__ rx_h, double *__restrict__ v, const long long *__restrict__ cptr,
+    const int *__restrict__ cidx, const double *__restrict__ rval, int *lcnt, int *lrow,
+    double *lval)
 {
     __shared__ int s_b[SP_LCAP];
     __shared__ double s_coef[SP_LCAP];
     __shared__ double s_gamma[R_];
     __shared__ int s_cnt;
+    // (a primal step's ratio partials are fetched beside the control block; a dual step does not
+    // use them)
+    const DzgCand2 cw = reduce_partials(rx_r, rx_k, rx_h, nparts);
     DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     int p;
     if (c.kind == DZG_STEP_PRIMAL) {
         const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-        const DzgCand2 cw = reduce_partials(rx_r, rx_k, rx_h, nparts);
         if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_UNBOUNDED)) return;
         p = cw.k;
         if (lead) ctl->leave_pos = p;
@@ -288,6 +372,17 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     const int rl = bp >= 0 ? -1 : -1 - bcode[p]; // row whose slack is basic at p
     const int tid = threadIdx.x, stride = gridDim.x * blockDim.x;
     const int gid = blockIdx.x * blockDim.x + tid;
+    // live-entry lists of the columns (k_price_csc_rl): the leaving slack's row carries v = 1 in
+    // the pricing pass that follows and joins R at this pivot: its entries join their columns'
+    // lists here (a row has at most one entry per column: no two threads share a list)
+    if (lcnt && rl >= 0 && blockIdx.x == 0)
+        for (long long e = rptr[rl] + tid; e < rptr[rl + 1]; e += blockDim.x) {
+            const int col = cidx[e];
+            const long long at = cptr[col] + lcnt[col];
+            lrow[at] = rl;
+            lval[at] = rval[e];
+            lcnt[col] += 1;
+        }
     // rows outside R: zero, except the leaving slack's own row
     for (int r = gid; r < m; r += stride)
         if (dslot[r] < 0) v[r] = (r == rl) ? 1.0 : 0.0;
@@ -319,15 +414,33 @@ __global__ __launch_bounds__(256) void k_sp_btran(
         if (tid == 0) s_cnt = total;
         __syncthreads();
         const int cnt = s_cnt;
-        if (tid < neta) {
+        if (tid < neta) { // (gathers four at a time, the sums in list order)
             double g = s_gamma[tid];
-            for (int i = 0; i < cnt; ++i) g = fma(s_coef[i], U[(long long)tid * ldu + s_b[i]], g);
+            const double *ut = U + (long long)tid * ldu;
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const double u0 = ut[s_b[i]], u1 = ut[s_b[i + 1]], u2 = ut[s_b[i + 2]], u3 = ut[s_b[i + 3]];
+                g = fma(s_coef[i], u0, g);
+                g = fma(s_coef[i + 1], u1, g);
+                g = fma(s_coef[i + 2], u2, g);
+                g = fma(s_coef[i + 3], u3, g);
+            }
+            for (; i < cnt; ++i) g = fma(s_coef[i], ut[s_b[i]], g);
             s_gamma[tid] = g;
         }
         int slot = 0;
         for (int cc = gid; cc < k && slot < 4; cc += stride, ++slot) {
             double a = acc[slot];
-            for (int i = 0; i < cnt; ++i) a = fma(s_coef[i], X[(long long)s_b[i] * ldb + cc], a);
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const double x0 = X[(long long)s_b[i] * ldb + cc], x1 = X[(long long)s_b[i + 1] * ldb + cc],
+                             x2 = X[(long long)s_b[i + 2] * ldb + cc], x3 = X[(long long)s_b[i + 3] * ldb + cc];
+                a = fma(s_coef[i], x0, a);
+                a = fma(s_coef[i + 1], x1, a);
+                a = fma(s_coef[i + 2], x2, a);
+                a = fma(s_coef[i + 3], x3, a);
+            }
+            for (; i < cnt; ++i) a = fma(s_coef[i], X[(long long)s_b[i] * ldb + cc], a);
             acc[slot] = a;
         }
     }
@@ -340,8 +453,17 @@ __global__ __launch_bounds__(256) void k_sp_btran(
         } else { // more than 4 columns per thread (k > 4 * grid threads = 1 M): not reachable
             a = 0.0;
         }
-        for (int t = 0; t < neta; ++t) a = fma(-s_gamma[t], W[(long long)t * ldw + cc], a);
-        v[drow[cc]] = a;
+        const int vr = drow[cc];
+        int t = 0;
+        for (; t + 8 <= neta; t += 8) { // (eight coalesced loads side by side, the sum in order)
+            double w[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) w[g] = W[(long long)(t + g) * ldw + cc];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) a = fma(-s_gamma[t + g], w[g], a);
+        }
+        for (; t < neta; ++t) a = fma(-s_gamma[t], W[(long long)t * ldw + cc], a);
+        v[vr] = a;
     }
 }
 
@@ -354,7 +476,8 @@ __device__ __forceinline__ int sp_pivot_books(
     const double *__restrict__ dz, int *basis, int *nonbasis, const int *__restrict__ var_col,
     int *drow, int *dslot, int *sslot, int *spos, int *bslot, int *rowpos, int *plist, int *pslot,
     const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
-    double *log_mu, double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode)
+    double *log_mu, double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode,
+    bool live_lists)
 {
     const double xp = x[p], xbp = xbar[p], dxp = dx[p];
     const double zr = z[r], zbr = zbar[r], dzr = dz[r];
@@ -441,7 +564,10 @@ __device__ __forceinline__ int sp_pivot_books(
         log_margin[it] = c.margin;
     }
     long long ns = c.nb_struct;
-    ctl->price_bytes = c.price_bytes + 12.0 * (double)c.nb_nnz + 4.0 * (double)(ns + 1) +
+    // (live-entry pricing: the 12 bytes per walked entry are counted by the kernel itself, rl_work)
+    ctl->price_bytes = c.price_bytes +
+                       (live_lists ? 20.0 * (double)ns
+                                   : 12.0 * (double)c.nb_nnz + 4.0 * (double)(ns + 1)) +
                        8.0 * (double)m + 32.0 * (double)q;
     basis[p] = vj;
     nonbasis[r] = vi;
@@ -498,7 +624,8 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
     const long long *__restrict__ cptr, const int *__restrict__ ridx,
     const double *__restrict__ cval, const long long *__restrict__ rptr, int *bcnt, int *bcol,
     double *bval, int *log_kind, int *log_enter, int *log_leave, double *log_mu,
-    double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode)
+    double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode,
+    const int *__restrict__ cidx, int *lcnt, int *lrow, double *lval)
 {
     __shared__ int s_ok, s_ci, s_cj;
     const DzgCtl c = *ctl;
@@ -511,7 +638,7 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
         s_ok = sp_pivot_books(ctl, c, m, q, p, r, c.neta, vi, vj, s_ci, s_cj, x, xbar, z, zbar, dx, dz,
                               basis, nonbasis, var_col, drow, dslot, sslot, spos, bslot, rowpos,
                               plist, pslot, cptr, log_kind, log_enter, log_leave, log_mu,
-                              log_margin, log_cap, bcode, nbcode, pcode);
+                              log_margin, log_cap, bcode, nbcode, pcode, lcnt != nullptr);
     }
     __syncthreads();
     if (!s_ok) return;
@@ -541,6 +668,23 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
             bval[rptr[row] + n] = cval[e];
             bcnt[row] = n + 1;
         }
+    // live-entry lists of the columns: the entering slack's row leaves R (the leaving slack's row
+    // joined in k_sp_btran).  The last entry of a list moves into the hole.
+    if (lcnt && cj < 0) {
+        const int re = -1 - cj;
+        for (long long e = rptr[re] + threadIdx.x; e < rptr[re + 1]; e += blockDim.x) {
+            const int col = cidx[e];
+            const long long base = cptr[col];
+            const int n = lcnt[col];
+            for (int i = 0; i < n; ++i)
+                if (lrow[base + i] == re) {
+                    lrow[base + i] = lrow[base + n - 1];
+                    lval[base + i] = lval[base + n - 1];
+                    break;
+                }
+            lcnt[col] = n - 1;
+        }
+    }
 }
 
 
@@ -558,10 +702,23 @@ __global__ __launch_bounds__(256) void k_sp_update(
     long long ldw, double *__restrict__ X, long long ldb, const int *__restrict__ drow,
     const int *__restrict__ spos)
 {
+    // this thread's first element of each vector leaves beside the control block (nothing here is
+    // written by another thread of this launch): one trip instead of two
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    double x_f = 0.0, xb_f = 0.0, dx_f = 0.0, z_f = 0.0, zb_f = 0.0, dz_f = 0.0;
+    if (gid < m) {
+        x_f = x[gid];
+        xb_f = xbar[gid];
+        if (!only_partials) dx_f = dx[gid];
+    }
+    if (gid < q) {
+        z_f = z[gid];
+        zb_f = zbar[gid];
+        if (!only_partials) dz_f = dz[gid];
+    }
     const DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
     const int p = c.leave_pos, r = c.enter_pos;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (!only_partials) {
         const int ko = c.sp_k, kn = c.ncompact, last = ko - 1;
         const int nold = c.neta - 1; // pending etas before this pivot
@@ -610,9 +767,9 @@ __global__ __launch_bounds__(256) void k_sp_update(
     const double tau = c.tau, inf = __builtin_inf();
     DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
     for (int i = gid; i < m; i += stride) {
-        double xi = x[i], xb = xbar[i];
+        double xi = i == gid ? x_f : x[i], xb = i == gid ? xb_f : xbar[i];
         if (!only_partials) {
-            const double d = dx[i];
+            const double d = i == gid ? dx_f : dx[i];
             const double a = t * d, b = tbar * d;
             xi = (i == p) ? t : xi - a;
             xb = (i == p) ? tbar : xb - b;
@@ -629,9 +786,9 @@ __global__ __launch_bounds__(256) void k_sp_update(
         if (fabs(xb) <= tau && !(xi > tau)) bx.h = inf;
     }
     for (int kk = gid; kk < q; kk += stride) {
-        double zk = z[kk], zb = zbar[kk];
+        double zk = kk == gid ? z_f : z[kk], zb = kk == gid ? zb_f : zbar[kk];
         if (!only_partials) {
-            const double d = dz[kk];
+            const double d = kk == gid ? dz_f : dz[kk];
             const double a = s * d, b = sbar * d;
             zk = (kk == r) ? s : zk - a;
             zb = (kk == r) ? sbar : zb - b;
@@ -665,6 +822,7 @@ __global__ __launch_bounds__(256) void k_sp_update(
 // ---------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+#define SPF_LD 80 // LDS row stride of the W tile in doubles: rows t and t + 1 sixteen banks apart
 __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double *__restrict__ X,
                                                        long long ldb, const double *__restrict__ U,
                                                        long long ldu, const double *__restrict__ W,
@@ -672,34 +830,48 @@ __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double
 {
     // (a flush folds a FULL eta file, like k_fast_flush_mfma: one enqueued behind an iteration that
     // did not pivot is a no-op)
+    __shared__ double s_w[R_ * SPF_LD];
     const int neta = ctl->neta, k = ctl->ncompact;
     if (neta < R_ || k <= 0 || ctl->status != DZG_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64;
     const int i0 = (blockIdx.y * 4 + wave) * 16;
-    if (c0 >= k || i0 >= k) return;
+    if (c0 >= k || blockIdx.y * 64 >= k) return; // (workgroup-uniform: the barrier below is safe)
     const int li = lane & 15, lk = lane >> 4;
+    // Everything the workgroup needs leaves in ONE trip: the 64 x 64 tile of W the four waves share
+    // (through LDS), this wave's 16 x 64 strip of U^T and its 16 x 64 strip of X.  (Step by step --
+    // a load, a wait, four MFMAs, sixteen times over -- a flush took 537 us at k = 4 126 where X
+    // streams in 50.)  Rows / columns beyond k are clamped to k - 1: a row of the product depends
+    // on its own row of U only, a column on its own column of W, and neither is stored.
+    double wreg[16];
+    {
+        const int c = min(c0 + lane, k - 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wreg[i] = W[(long long)(wave + 4 * i) * ldw + c];
+    }
+    double a[16];
+    {
+        const int arow = min(i0 + li, k - 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) a[s4] = -U[(long long)(4 * s4 + lk) * ldu + arow];
+    }
     double4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
-            acc[j][g] = (row < k && col < k) ? X[(long long)row * ldb + col] : 0.0;
+            const int row = min(i0 + lk + 4 * g, k - 1), col = min(c0 + 16 * j + li, k - 1);
+            acc[j][g] = X[(long long)row * ldb + col];
         }
-    const int arow = i0 + li;
-    // (step by step: fetching all 80 operands of the tile up front, as k_fast_flush_mfma does, measured
-    // 366 us against 131 us per flush at k = 1 175 here -- the masks on W cost registers and waves)
-    const int ksteps = (neta + 3) >> 2;
-    for (int s = 0; s < ksteps; ++s) {
-        const int t = 4 * s + lk;
-        const double a = (arow < k && t < neta) ? -U[(long long)t * ldu + arow] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = c0 + 16 * j + li;
-            const double b = (t < neta && col < k) ? W[(long long)t * ldw + col] : 0.0;
-            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
-        }
+    for (int i = 0; i < 16; ++i) s_w[(wave + 4 * i) * SPF_LD + lane] = wreg[i];
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+        const int t = 4 * s4 + lk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], s_w[t * SPF_LD + 16 * j + li], acc[j], 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -768,6 +940,27 @@ __global__ __launch_bounds__(256) void k_sp_lists(int m, const long long *__rest
     }
 }
 
+// live-entry lists from scratch (creation, after a refactorisation): column j keeps, in CSC
+// order, its entries in rows of R (dslot >= 0).  grid over columns.
+__global__ __launch_bounds__(256) void k_sp_rlists(int ns, const long long *__restrict__ cptr,
+                                                   const int *__restrict__ ridx,
+                                                   const double *__restrict__ cval,
+                                                   const int *__restrict__ dslot, int *lcnt,
+                                                   int *lrow, double *lval)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ns; j += gridDim.x * blockDim.x) {
+        const long long e0 = cptr[j];
+        int n = 0;
+        for (long long e = e0; e < cptr[j + 1]; ++e)
+            if (dslot[ridx[e]] >= 0) {
+                lrow[e0 + n] = ridx[e];
+                lval[e0 + n] = cval[e];
+                ++n;
+            }
+        lcnt[j] = n;
+    }
+}
+
 // after a refactorisation: Xinv (row b = b-th structural basic in position order, column a =
 // compact column a) becomes X.  grid (ceil(k / 256), k)
 __global__ __launch_bounds__(256) void k_sp_ref_copy(int k, const double *__restrict__ Xinv,
@@ -791,6 +984,9 @@ void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st)
                        d.sslot, d.spos, d.bslot, d.rowpos, first ? d.acol_code : (int *)nullptr);
     hipLaunchKernelGGL(k_sp_lists, dim3(sp_grid(d.m)), dim3(256), 0, st, d.m, d.rptr, d.cidx, d.rval,
                        d.bslot, d.bcnt, d.bcol, d.bval);
+    if (d.lcnt)
+        hipLaunchKernelGGL(k_sp_rlists, dim3(sp_grid(d.ns)), dim3(256), 0, st, d.ns, d.cptr, d.ridx,
+                           d.cval, d.dslot, d.lcnt, d.lrow, d.lval);
 }
 
 // need_kind = PRIMAL: the head of the iteration (status + primal FTRAN); DUAL: after pricing
@@ -818,7 +1014,8 @@ void dzg_launch_sp_btran(const DzgDev &d, hipStream_t st)
     const int nparts = 2 * sp_grid(d.m);
     hipLaunchKernelGGL(k_sp_btran, dim3(sp_grid(d.m)), dim3(256), 0, st, d.ctl, d.m, nparts, d.rptr,
                        d.bcnt, d.bcol, d.bval, d.bslot, d.sslot, d.bcode, d.binv, d.ldb, d.U,
-                       d.ldw, d.W, d.ldw, d.drow, d.dslot, d.rx_r, d.rx_k, d.rx_h, d.v);
+                       d.ldw, d.W, d.ldw, d.drow, d.dslot, d.rx_r, d.rx_k, d.rx_h, d.v, d.cptr, d.cidx,
+                       d.rval, d.lcnt, d.lrow, d.lval);
 }
 
 void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st)
@@ -827,7 +1024,7 @@ void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st)
                        d.zbar, d.dx, d.dz, d.basis, d.nonbasis, d.var_col, d.drow, d.dslot, d.sslot,
                        d.spos, d.bslot, d.rowpos, d.plist, d.pslot, d.cptr, d.ridx, d.cval, d.rptr, d.bcnt,
                        d.bcol, d.bval, d.log_kind, d.log_enter, d.log_leave, d.log_mu, d.log_margin,
-                       d.log_cap, d.bcode, d.nbcode, d.pcode);
+                       d.log_cap, d.bcode, d.nbcode, d.pcode, d.cidx, d.lcnt, d.lrow, d.lval);
 }
 
 void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st)
@@ -839,7 +1036,8 @@ void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st)
 
 void dzg_launch_sp_flush(const DzgDev &d, hipStream_t st)
 {
-    const int kmax = d.m; // k <= m; the kernel masks by the device's k
+    // k <= k_hint <= m (the host's bound for the batch in flight); the kernel masks by the device's k
+    const int kmax = d.k_hint > 0 && d.k_hint < d.m ? d.k_hint : d.m;
     hipLaunchKernelGGL(k_sp_flush_mfma, dim3((kmax + 63) / 64, (kmax + 63) / 64), dim3(256), 0, st,
                        d.ctl, d.binv, d.ldb, d.U, d.ldw, d.W, d.ldw);
     hipLaunchKernelGGL(k_sp_flush_done, dim3(1), dim3(1), 0, st, d.ctl);

@@ -456,6 +456,11 @@ int dzg_solver_set_budget(dzg_solver *s, int64_t max_new_iters);
 int dzg_debug_hold_cus(int32_t device, int32_t workgroups, double seconds);
 int dzg_debug_hold_wait(void);
 
+/* Test hook: checks the live-entry lists the sparse-basis pricing pass walks (csrc/k_sparse.hip,
+ * k_price_csc_rl) against their definition; returns the number of columns whose list is wrong
+ * (0 = consistent), < 0 on error (no such lists: DZG_E_ARG); *entries = entries listed in all. */
+int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries);
+
 /* Deterministic max-loc merge: largest ratio wins, lowest global position on ties --
  * the sequential first-wins rule of src/simplex.rs:432-435,456-459.  Returns the index
  * of the winning record, or -1 when every record is empty. */

@@ -241,8 +241,11 @@ def test_config4_fast_run_invariants(core, sparse_lp):
             slack[var - NS4] = res.x[pos]
     a = sp.csc_matrix((val, ri, cp), shape=(M4, NS4))
     assert np.abs(a @ xs + slack - b).max() <= 1e-9
+    # pricing walks the live entries only (rows with a nonbasic slack: at most 1000 of them so far,
+    # ~2 * PER_COL4 entries each) beside its per-column and per-position constants
     per_launch = res.price_bytes / res.iterations
-    assert 12 * (NS4 - 1000) * PER_COL4 <= per_launch <= 12 * NS4 * PER_COL4 + 36 * NS4 + 8 * M4
+    assert 20 * (NS4 - 1000) + 8 * M4 + 32 * NS4 <= per_launch
+    assert per_launch <= 20 * NS4 + 8 * M4 + 32 * NS4 + 12 * 1000 * 4 * PER_COL4
     # a budgeted continuation resumes the same trajectory: same log as an uninterrupted run
     with core.Solver(lp, numerics=core.FAST, poll_interval=64) as s2:
         assert s2.run(300) == "iter_limit" and s2.run(700) == "iter_limit"

@@ -1012,6 +1012,70 @@ def test_sparse_basis_path_leaves_the_oracle_path_only_where_it_flagged_a_near_t
     assert not bad_auto, bad_auto
 
 
+def _live_lists_bad(s):
+    import ctypes as C
+
+    from dantzig_amd import _ffi
+
+    entries = C.c_int64(0)
+    bad = _ffi.lib().dzg_debug_live_lists(s._h, C.byref(entries))
+    assert bad >= 0, _ffi.lib().dzg_last_error()
+    return bad, entries.value
+
+
+def test_live_entry_pricing_keeps_its_lists_and_agrees_with_the_full_pass(core, monkeypatch):
+    """The sparse-basis path prices over the LIVE entries of a column only (rows whose slack is
+    nonbasic, csrc/k_price_kernels.h k_price_csc_rl): the lists are kept by k_sp_btran (a leaving
+    slack's row joins) and k_sp_pivot (an entering slack's row goes), rebuilt at a refactorisation.
+    After every few pivots the lists equal their definition (host recomputation through the test
+    hook); the solve is the one the full pass (DZG_SP_PRICE_FULL=1: every stored entry) takes --
+    same status and pivot log wherever neither flagged a near tie, same objective to 1e-9."""
+    import scipy.sparse as sp
+
+    from tests.lp_families import log3, make_lp
+
+    cases = []
+    for seed in range(8800, 8830):
+        a, b, c = make_lp(seed, seed % 3, 2, 60)
+        acsc = sp.csc_matrix(a)
+        acsc.eliminate_zeros()
+        acsc.sort_indices()
+        cases.append((seed, core.CoreLP.from_csc(a.shape[0], acsc.indptr, acsc.indices, acsc.data, b, c), 0))
+    for seed, m, ns, per_col, interval in [(8901, 300, 800, 5, 0), (8902, 500, 1200, 8, 0),
+                                           (8903, 256, 700, 6, 41)]:
+        cp, ri, val, b, c = core.gen_sparse_lp(seed, m, ns, per_col)
+        cases.append((seed, core.CoreLP.from_csc(m, cp, ri, val, b, c), interval))
+    most = 0
+    for seed, lp, interval in cases:
+        monkeypatch.delenv("DZG_SP_PRICE_FULL", raising=False)
+        with core.Solver(lp, numerics=core.FAST, poll_interval=8, refactor_interval=interval) as s:
+            chunks = 0
+            while s.run(29) == "iter_limit" and chunks < 400:
+                bad, entries = _live_lists_bad(s)
+                assert bad == 0, (seed, chunks, bad)
+                most = max(most, entries)
+                chunks += 1
+            live = s.result()
+            bad, _ = _live_lists_bad(s)
+            # (a dual step that ends at its ratio test -- infeasible, or stopped at a near tie -- has
+            # already listed the leaving slack's row, which then never joined R: a final state)
+            assert bad == 0 or live.status in ("infeasible", "near_tie", "panic"), (seed, "end", bad, live.status)
+        monkeypatch.setenv("DZG_SP_PRICE_FULL", "1")
+        with core.Solver(lp, numerics=core.FAST, poll_interval=8, refactor_interval=interval) as s:
+            chunks = 0
+            while s.run(29) == "iter_limit" and chunks < 400:
+                chunks += 1
+            with pytest.raises(AssertionError):
+                _live_lists_bad(s)  # (no lists are kept in this mode: the hook says so)
+            full = s.result()
+        if live.near_ties == 0 and full.near_ties == 0:
+            assert live.status == full.status, seed
+            assert log3(live.pivots) == log3(full.pivots), seed
+        if live.status == full.status == "optimal":
+            assert abs(live.objective - full.objective) <= 1e-9 * max(1.0, abs(full.objective)), seed
+    assert most > 0  # (some row did join R somewhere)
+
+
 # ------------------------------------------------------------------ three launches == seven launches
 def _same_solution(r, w):
     return (r.status == w.status and r.iterations == w.iterations and r.pivots == w.pivots
