@@ -363,6 +363,12 @@ struct DzgDev {
     int repl;            // 1: every structural column is resident (A points at column col0 of the
                          //    whole matrix, so `A + (code - col0) * lda` reaches any column)
     long long xstride;   // exchange record stride in doubles (8: header only, repl)
+    // row-wise pricing of a dense matrix (k_price_rows, k_price_kernels.h); At == NULL: not kept
+    const double *At;    // row-major copy of the local structural block: m rows of ldt
+    long long ldt;       // >= col1 - col0, a multiple of 4; the padding columns are zero
+    double *ppart;       // [PR_GMAX][ldt] partial sums of the row groups
+    int rows_T;          // the row-wise pass prices an iteration while ctl->ncompact < rows_T
+    int k_lo_hint;       // a LOWER bound of ctl->ncompact for the batch being enqueued; -1: unknown
     int k_hint;          // an UPPER BOUND of ctl->ncompact while the enqueued batch runs (the host's
                          // last reading + the batch: k grows by at most one per pivot); 0: unknown
                          // (= m).  Sizes the eta flush's grid: k is only known on the device, and a
@@ -400,6 +406,9 @@ int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *
 // k_price.hip
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st);
+void dzg_launch_transpose_to_rows(const double *A, long long lda, int m, int n, double *At,
+                                  long long ldt, hipStream_t st);
+int dzg_price_rows_groups(void);
 int dzg_price_partials(int kernel);
 int dzg_price_partials_dev(const DzgDev &d, int kernel);
 #define DZG_PRICE_CSC_KERNEL 100 // internal id: the CSC pricing kernel

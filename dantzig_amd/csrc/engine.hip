@@ -636,6 +636,27 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                 HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * DZG_CHAIN_BAR_WORDS, s->st));
             }
         }
+        // Row-wise pricing (k_price_kernels.h): a row-major copy of the rank's own columns and the
+        // partial sums of the row groups.  AUTO pricing only (an explicit kernel choice means that
+        // kernel); DZG_PRICE_ROWS=0 is the A/B switch of the tools and tests.
+        {
+            const char *rows_env = std::getenv("DZG_PRICE_ROWS");
+            const int nown = d.col1 - d.col0;
+            if (!d.csc && o.price_kernel == DZG_PRICE_AUTO && m > 0 && nown > 0 && ns > 0 &&
+                !(rows_env && rows_env[0] == '0')) {
+                d.ldt = ((long long)nown + 3) / 4 * 4;
+                double *at = nullptr;
+                TRY(dev_alloc(s, &at, (size_t)m * (size_t)d.ldt));
+                TRY(dev_alloc(s, &d.ppart, (size_t)dzg_price_rows_groups() * (size_t)d.ldt));
+                dzg_launch_transpose_to_rows(d.A, d.lda, m, nown, at, d.ldt, s->st);
+                d.At = at;
+                // where 8 (k + 1) n_s bytes of rows meet 8 m (n_s - k) bytes of columns, less the
+                // second launch: a function of the problem's shape alone (the same on every rank)
+                d.rows_T = (int)(0.9 * (double)m * (double)ns / ((double)ns + (double)m));
+                if (const char *t = std::getenv("DZG_PRICE_ROWS_T")) d.rows_T = std::atoi(t);
+                if (d.rows_T < 1) d.At = nullptr;
+            }
+        }
         dzg_launch_fast_init(d, s->st);
         if (d.spb) {
             dzg_launch_sp_init(d, 1, s->st);
@@ -988,6 +1009,7 @@ static int run_fast(dzg_solver *s)
         // Only around launches this loop enqueues itself: the phase entry points are also driven
         // from outside (sharded hosts), where nobody refreshes the bound
         const int k_bound = (int)s->h_ctl->ncompact + batch;
+        const int k_low = (int)s->h_ctl->ncompact > batch ? (int)s->h_ctl->ncompact - batch : 0;
         if (s->d.spb) {
             s->d.k_hint = k_bound;
             for (int b = 0; b < batch; ++b) enqueue_sparse_iteration(s, b);
@@ -1010,11 +1032,12 @@ static int run_fast(dzg_solver *s)
             s->batch_chain = s->chain_bar && s->h_ctl->iter >= s->chain_retry_iter &&
                              (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
             s->d.k_hint = k_bound;
+            s->d.k_lo_hint = k_low;
             if (s->batch_chain)
                 for (int b = 0; b < batch; ++b) enqueue_chain_iteration(s, b);
             else
                 for (int b = 0; b < batch; ++b) enqueue_fast_iteration(s, b);
-            s->d.k_hint = 0;
+            s->d.k_hint = s->d.k_lo_hint = 0;
         }
         s->since_refactor += batch;
         TRY(read_ctl(s));
@@ -1099,6 +1122,7 @@ static int set_budget(dzg_solver *s, int64_t max_new_iters)
     if (s->d.repl && s->cols_present != s->d.ns)
         return fail(DZG_E_ARG, "replicate_matrix: " + std::to_string(s->d.ns - s->cols_present) +
                                " structural columns have not been uploaded (dzg_solver_upload_columns)");
+    s->d.k_hint = s->d.k_lo_hint = 0; // (bounds of a batch that ended in an error are void)
     TRY(read_ctl(s));
     DzgCtl *h = s->h_ctl;
     if (h->status != DZG_RUNNING && h->status != DZG_ITER_LIMIT && h->status != DZG_NEAR_TIE)
@@ -1291,6 +1315,8 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         s->since_refactor += batch;
         s->batch_chain = s->chain_bar && (long long)s->h_ctl->ncompact + batch <= s->chain_kcap;
         s->d.price_cols_hint = (int)s->h_ctl->nb_struct + batch;
+        s->d.k_hint = (int)s->h_ctl->ncompact + batch; // bounds on k for the launches of this batch
+        s->d.k_lo_hint = (int)s->h_ctl->ncompact > batch ? (int)s->h_ctl->ncompact - batch : 0;
         for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
@@ -1306,6 +1332,7 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
             TRY(dzg_shard_phase3(s, s->xrecv2));
         }
         s->prof_slot = -1;
+        s->d.k_hint = s->d.k_lo_hint = 0;
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
         if (s->h_ctl->bar_timeout)
@@ -1364,6 +1391,8 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
             sv[r]->batch_chain =
                 sv[r]->chain_bar && (long long)sv[r]->h_ctl->ncompact + batch <= sv[r]->chain_kcap;
             sv[r]->d.price_cols_hint = (int)sv[r]->h_ctl->nb_struct + batch;
+            sv[r]->d.k_hint = (int)sv[r]->h_ctl->ncompact + batch;
+            sv[r]->d.k_lo_hint = (int)sv[r]->h_ctl->ncompact > batch ? (int)sv[r]->h_ctl->ncompact - batch : 0;
         }
         for (int b = 0; b < batch; ++b) {
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));
@@ -1372,6 +1401,7 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
             TRY(exchange(true));
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase3(sv[r], sv[r]->xrecv2));
         }
+        for (int r = 0; r < world; ++r) sv[r]->d.k_hint = sv[r]->d.k_lo_hint = 0;
         for (int r = 0; r < world; ++r) TRY(read_ctl(sv[r]));
         HIP_OK(hipGetLastError());
         for (int r = 0; r < world; ++r)

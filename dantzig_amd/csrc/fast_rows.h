@@ -188,6 +188,8 @@ struct DzgPivotArgs {
     int *log_kind, *log_enter, *log_leave;
     double *log_mu, *log_margin;
     long long log_cap;
+    int rows_T;        // row-wise pricing while ncompact < rows_T (0: never), rows of rows_ld doubles
+    long long rows_ld;
 };
 
 inline DzgPivotArgs dzg_pivot_args(const DzgDev &d)
@@ -202,6 +204,7 @@ inline DzgPivotArgs dzg_pivot_args(const DzgDev &d)
     pa.col0 = d.col0; pa.col1 = d.col1; pa.cptr = d.csc ? d.cptr : nullptr;
     pa.log_kind = d.log_kind; pa.log_enter = d.log_enter; pa.log_leave = d.log_leave;
     pa.log_mu = d.log_mu; pa.log_margin = d.log_margin; pa.log_cap = d.log_cap;
+    pa.rows_T = d.At ? d.rows_T : 0; pa.rows_ld = d.ldt;
     return pa;
 }
 
@@ -347,7 +350,15 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
     double bytes = c.price_bytes;
     if (cptr)
         bytes += 12.0 * (double)c.nb_nnz + 4.0 * (double)(s + 1) + 8.0 * (double)m + 32.0 * (double)q;
-    else
+    else if (pa.rows_T > 0 && c.ncompact < pa.rows_T) {
+        // row-wise pass: k (+ 1) rows of the row-major copy, the groups' partial sums written and
+        // read once, v's k coefficients, and the per-position part as below
+        const double nrows = (double)c.ncompact + (ci < 0 ? 1.0 : 0.0); // (a leaving slack's own row)
+        double G = ceil(nrows / 16.0);
+        G = G < 1.0 ? 1.0 : (G > 32.0 ? 32.0 : G);
+        bytes += 8.0 * nrows * (double)pa.rows_ld + 16.0 * G * (double)pa.rows_ld + 12.0 * nrows +
+                 32.0 * (double)q;
+    } else
         bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
     ctl->price_bytes = bytes;
     basis[p] = vj;

@@ -15,7 +15,7 @@ static int resolve(int kernel)
 static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
                         const int *plist, const int *nonbasis, const int *var_col, const double *v,
                         double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
-                        double *rz_h, int col0, const int *pcode, hipStream_t st)
+                        double *rz_h, int col0, const int *pcode, hipStream_t st, int rows_T = 0)
 {
     const dim3 grid(DZG_PRICE_TREE_BLOCKS), block(256);
     const int per_wave = (ncols + 4 * DZG_PRICE_TREE_BLOCKS - 1) / (4 * DZG_PRICE_TREE_BLOCKS);
@@ -30,7 +30,7 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
     const int passes = (per_wave + 15) / 16;
     const int cw = passes > 0 ? (per_wave + passes - 1) / passes : 1;
 #define TREE(CW, DEPTH, TP)                                                                          \
-    hipLaunchKernelGGL((k_price_tree<CW, DEPTH, TP>), grid, block, 0, st, PRICE_ARGS, pcode)
+    hipLaunchKernelGGL((k_price_tree<CW, DEPTH, TP>), grid, block, 0, st, PRICE_ARGS, pcode, rows_T)
     // (15-16 columns per wave: two passes of 8 with 2-KiB visits, 160.8 us against 162.7 for one pass
     // of 16 at 8192 rows, profiles/r02_price_microbench_adjacent_tiles.txt)
     if (per_wave == 15 || per_wave == 16) { TREE(8, 2, 2); return; }
@@ -58,11 +58,11 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
 static void launch(int kernel, int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
                    const int *plist, const int *nonbasis, const int *var_col, const double *v,
                    double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
-                   double *rz_h, int col0, const int *pcode, hipStream_t st)
+                   double *rz_h, int col0, const int *pcode, hipStream_t st, int rows_T = 0)
 {
     if (q <= 0) return;
     if (resolve(kernel) == DZG_PRICE_TREE)
-        launch_tree(ncols, PRICE_ARGS, pcode, st);
+        launch_tree(ncols, PRICE_ARGS, pcode, st, rows_T);
     else if (resolve(kernel) == DZG_PRICE_WAVE)
         hipLaunchKernelGGL((k_price_wave2<4>), dim3(DZG_PRICE_WAVE_BLOCKS), dim3(256), 0, st, ctl, A,
                            lda, m, q, plist, nonbasis, var_col, v, dz, z, zbar, rz_r, rz_k, rz_h, col0);
@@ -114,6 +114,16 @@ void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st)
            nullptr, nullptr, nullptr, nullptr, 0, nullptr, st);
 }
 
+// row-major copy of the local structural block for the row-wise pass
+void dzg_launch_transpose_to_rows(const double *A, long long lda, int m, int n, double *At,
+                                  long long ldt, hipStream_t st)
+{
+    if (m <= 0 || ldt <= 0) return;
+    hipLaunchKernelGGL(k_transpose_to_rows, dim3((unsigned)((ldt + 31) / 32), (unsigned)((m + 31) / 32)),
+                       dim3(32, 8), 0, st, A, lda, m, n, At, ldt);
+}
+int dzg_price_rows_groups(void) { return PR_GMAX; }
+
 // FAST numerics: structural positions from plist, ratio-test partials for the dual step
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
 {
@@ -135,8 +145,26 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
     // (the kernel takes the exact count from the control block: a stale hint costs speed only)
     int ncols = d.col1 - d.col0;
     if (d.price_cols_hint > 0 && d.price_cols_hint < ncols) ncols = d.price_cols_hint;
+    int rows_T = 0;
+    if (d.At && d.q > 0 && resolve(kernel) == DZG_PRICE_TREE) {
+        // row-wise while k < rows_T (k_price_kernels.h).  The kernels apply the rule themselves; the
+        // host's bounds on k (valid for the batch it is enqueueing, else unknown) only spare the
+        // launches that cannot apply
+        rows_T = d.rows_T;
+        const bool rows_possible = d.k_lo_hint < 0 || d.k_lo_hint < rows_T;
+        const bool cols_possible = d.k_hint <= 0 || d.k_hint >= rows_T;
+        if (rows_possible) {
+            hipLaunchKernelGGL((k_price_rows<4>), dim3((unsigned)((d.ldt + 1023) / 1024), PR_GMAX),
+                               dim3(256), 0, st, d.ctl, rows_T, d.At, d.ldt, d.drow, d.bcode, d.v,
+                               d.ppart);
+            hipLaunchKernelGGL(k_price_rows_finish, dim3(DZG_PRICE_TREE_BLOCKS), dim3(256), 0, st,
+                               d.ctl, rows_T, d.ppart, d.ldt, d.q, d.plist, d.pcode, d.nbcode, d.bcode,
+                               d.col0, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h);
+        }
+        if (!cols_possible) return;
+    }
     launch(kernel, ncols, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nbcode, nullptr, d.v, d.dz, d.z,
-           d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, d.pcode, st);
+           d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, d.pcode, st, rows_T);
 }
 
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,

@@ -379,10 +379,11 @@ __global__ __launch_bounds__(256) void k_price_tree(
     const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
     int *__restrict__ rz_k, double *__restrict__ rz_h, int col0 = 0,
-    const int *__restrict__ pcode = nullptr)
+    const int *__restrict__ pcode = nullptr, int rows_T = 0)
 {
     constexpr int TR = 128;
     if (ctl && ctl->status != DZG_RUNNING) return;
+    if (rows_T > 0 && ctl->ncompact < rows_T) return; // the row-wise pass prices this iteration
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
     const int wg = blockIdx.x * 4 + wave;
@@ -821,6 +822,188 @@ __global__ __launch_bounds__(256) void k_price_csc_rl(
         __hip_atomic_fetch_add(work + blockIdx.x,
                                (unsigned long long)s_work[0] + s_work[1] + s_work[2] + s_work[3],
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------
+// Row-wise pricing of a DENSE matrix (FAST numerics, price_kernel = AUTO).
+//
+// v = row p of B^-1 is zero outside R -- the k rows whose slack is nonbasic, the rows of the
+// compact columns of the inverse (drow[0..k)) -- and the leaving slack's own row (k_fast_btran,
+// k_chain_pre: base 0 and eta rows that are zero there).  Early in a solve k is a small fraction
+// of m (k = 26..180 of 8192 rows over the benchmark's timed pivots, 4 050 after 150 000), and the
+// column-wise pass spends its 8 m bytes per column multiplying zeros.  With a second, ROW-major
+// copy of the matrix (At: m rows of ldt, one more GB at 8192 x 16384 of 288) the same numbers are
+//
+//      dz_j = - sum_{c < k} v[drow[c]] * At[drow[c]][j]  ( - At[rl][j], the leaving slack's row )
+//
+// i.e. (k + 1) contiguous rows streamed instead of m rows of every nonbasic column: 8 (k+1) n_s
+// bytes against 8 m (n_s - k).  Used while k < T = 0.9 m n_s / (n_s + m) (where the two byte
+// counts cross, less the second launch); beyond that the column-wise kernel takes over.  The
+// rule is evaluated ON THE DEVICE from ctl->ncompact by all three kernels alike (rows, finish,
+// columns: the ones that do not apply return at once), so the arithmetic a pivot gets depends on
+// the state alone; the host only leaves out launches its bounds on k prove idle.
+//
+// k_price_rows: grid (column tiles of 256 * VEC, PR_GMAX row groups).  G = min(PR_GMAX,
+// ceil(rows / 16)) groups are active; group g adds rows c = g, g + G, ... in ascending order
+// (16 rows = 16 x VEC x 8 B per lane in flight) and leaves its partial sums in part[g][j].
+// k_price_rows_finish: dz = -(part[0] + part[1] + ...) in group order for the nonbasic structural
+// positions, unit columns and the fused dual ratio test exactly as k_price_tree; 256 workgroups
+// = the tree kernel's count of ratio partials.  The order of a column's sum depends on k and the
+// compact numbering only (not on the grid, the tile width or a column sharding).
+// ---------------------------------------------------------------------------------
+#define PR_GMAX 32
+#define PR_BATCH 16
+template <int VEC>
+__global__ __launch_bounds__(256) void k_price_rows(
+    const DzgCtl *ctl, int rows_T, const double *__restrict__ At, long long ldt,
+    const int *__restrict__ drow, const int *__restrict__ bcode, const double *__restrict__ v,
+    double *__restrict__ part)
+{
+    typedef double vec_t __attribute__((ext_vector_type(2)));
+    __shared__ long long s_off[256];
+    __shared__ double s_coef[256];
+    const int status = ctl->status, k = ctl->ncompact, lp = ctl->leave_pos;
+    if (status != DZG_RUNNING || k >= rows_T) return;
+    const int lcode = lp >= 0 ? bcode[lp] : 0; // < 0: a slack leaves, row -1 - lcode carries v = 1
+    const int nrows = k + (lcode < 0 ? 1 : 0);
+    int G = (nrows + PR_BATCH - 1) / PR_BATCH;
+    G = G < 1 ? 1 : (G > PR_GMAX ? PR_GMAX : G);
+    const int g = blockIdx.y;
+    if (g >= G) return;
+    const long long j0 = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const bool live = j0 < ldt; // (ldt is a multiple of VEC)
+    const double *col = At + (live ? j0 : 0);
+    double acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+    for (int cbase = g; cbase < nrows; cbase += 256 * G) { // block-uniform
+        __syncthreads();
+        const int c = cbase + (int)threadIdx.x * G;
+        if (c < nrows) {
+            const int row = c < k ? drow[c] : -1 - lcode;
+            s_off[threadIdx.x] = (long long)row * ldt;
+            s_coef[threadIdx.x] = v[row];
+        }
+        __syncthreads();
+        const int left = (nrows - cbase + G - 1) / G;
+        const int n = left < 256 ? left : 256;
+        for (int i0 = 0; i0 < n; i0 += PR_BATCH) {
+            vec_t reg[PR_BATCH][VEC / 2];
+#pragma unroll
+            for (int u = 0; u < PR_BATCH; ++u)
+                if (i0 + u < n) {
+                    const double *src = col + s_off[i0 + u];
+#pragma unroll
+                    for (int h = 0; h < VEC / 2; ++h)
+                        reg[u][h] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(src) + h);
+                }
+#pragma unroll
+            for (int u = 0; u < PR_BATCH; ++u)
+                if (i0 + u < n) {
+                    const double cf = s_coef[i0 + u];
+#pragma unroll
+                    for (int h = 0; h < VEC / 2; ++h) {
+                        acc[2 * h] = fma(cf, reg[u][h].x, acc[2 * h]);
+                        acc[2 * h + 1] = fma(cf, reg[u][h].y, acc[2 * h + 1]);
+                    }
+                }
+        }
+    }
+    if (live) {
+        double *dst = part + (long long)g * ldt + j0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dst[e] = acc[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_price_rows_finish(
+    const DzgCtl *ctl, int rows_T, const double *__restrict__ part, long long ldt, int q,
+    const int *__restrict__ plist, const int *__restrict__ pcode, const int *__restrict__ nbcode,
+    const int *__restrict__ bcode, int col0, const double *__restrict__ v, double *__restrict__ dz,
+    const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
+    int *__restrict__ rz_k, double *__restrict__ rz_h)
+{
+    // first trip, side by side: the control block, this thread's position (unit columns) and its
+    // first list entry (plist / pcode hold q entries; those beyond nb_struct are stale and only
+    // used once the count has arrived)
+    const int nthreads = gridDim.x * blockDim.x;
+    const int spos = blockIdx.x * blockDim.x + threadIdx.x;
+    int scode = 0, pos0 = -1, code0 = -1;
+    if (spos < q) {
+        scode = nbcode[spos];
+        pos0 = plist[spos];
+        code0 = pcode[spos];
+    }
+    const int status = ctl->status, k = ctl->ncompact, lp = ctl->leave_pos;
+    const int count = (int)ctl->nb_struct;
+    const double mu = ctl->mu, tau = ctl->tau;
+    if (status != DZG_RUNNING || k >= rows_T) return;
+    const int lcode = lp >= 0 ? bcode[lp] : 0;
+    const int nrows = k + (lcode < 0 ? 1 : 0);
+    int G = (nrows + PR_BATCH - 1) / PR_BATCH;
+    G = G < 1 ? 1 : (G > PR_GMAX ? PR_GMAX : G);
+    DzgCand2 best = dzg_cand2_none();
+    double sv = 0.0, sz = 0.0, szb = 0.0;
+    if (scode < 0) {
+        sv = v[-1 - scode];
+        sz = z[spos];
+        szb = zbar[spos];
+    }
+    for (int idx = spos; idx < count; idx += nthreads) {
+        const int pos = idx == spos ? pos0 : plist[idx];
+        const int code = idx == spos ? code0 : pcode[idx];
+        if (code < 0) continue; // (the list holds structural columns only)
+        const double zc = z[pos], zbc = zbar[pos];
+        const double *src = part + (code - col0);
+        double sum = 0.0;
+        int gg = 0;
+        for (; gg + 8 <= G; gg += 8) { // eight partials side by side, added in group order
+            double t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = src[(long long)(gg + e) * ldt];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum = sum + t[e];
+        }
+        for (; gg < G; ++gg) sum = sum + src[(long long)gg * ldt];
+        dz[pos] = -sum;
+        price_candidate_v(best, -sum, pos, mu, tau, zc, zbc);
+    }
+    // ---- unit columns (the arithmetic of price_slack_positions)
+    if (scode < 0) {
+        const double p = 1.0 * -sv;
+        const double d = 0.0 + p;
+        dz[spos] = d;
+        price_candidate_v(best, d, spos, mu, tau, sz, szb);
+    }
+    for (int pos = spos + nthreads; pos < q; pos += nthreads) { // more positions than threads
+        const int code = nbcode[pos];
+        if (code < 0) {
+            const double p = 1.0 * -v[-1 - code];
+            const double d = 0.0 + p;
+            dz[pos] = d;
+            price_candidate(best, d, pos, mu, tau, z, zbar);
+        }
+    }
+    price_publish(best, rz_r, rz_k, rz_h);
+}
+
+// column-major m x n (lda) -> row-major m x ldt, 32 x 32 tiles through LDS; columns n..ldt-1 of a
+// row are zero.  grid (ceil(ldt / 32), ceil(m / 32)), block (32, 8).
+__global__ __launch_bounds__(256) void k_transpose_to_rows(const double *__restrict__ A, long long lda,
+                                                           int m, int n, double *__restrict__ At,
+                                                           long long ldt)
+{
+    __shared__ double tile[32][33];
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    for (int jj = threadIdx.y; jj < 32; jj += 8) {
+        const int j = j0 + jj, i = i0 + threadIdx.x;
+        tile[jj][threadIdx.x] = (j < n && i < m) ? A[(long long)j * lda + i] : 0.0;
+    }
+    __syncthreads();
+    for (int ii = threadIdx.y; ii < 32; ii += 8) {
+        const int i = i0 + ii, j = j0 + threadIdx.x;
+        if (i < m && j < ldt) At[(long long)i * ldt + j] = tile[threadIdx.x][ii];
+    }
 }
 
 #define DZG_PRICE_CSC_BLOCKS 2048

@@ -1076,6 +1076,51 @@ def test_live_entry_pricing_keeps_its_lists_and_agrees_with_the_full_pass(core, 
     assert most > 0  # (some row did join R somewhere)
 
 
+def test_row_wise_pricing_agrees_with_the_column_pass(core, monkeypatch):
+    """FAST with AUTO pricing prices an iteration ROW-wise while the compact width k is below
+    rows_T = 0.9 m n_s / (n_s + m) (csrc/k_price_kernels.h k_price_rows: v is zero outside the k
+    rows whose slack is nonbasic and the leaving slack's row, so k + 1 rows of a row-major copy
+    replace m rows of every column), column-wise beyond.  The same solve as with the column pass
+    alone (DZG_PRICE_ROWS=0): status, pivot log wherever neither run flagged a near tie, objective
+    to 1e-9, and the two computations of the pivot element (FTRAN's dx_p, pricing's -dz_r) agree
+    in both -- on the three LP families (k rises and falls across rows_T) and on a dense random LP
+    whose whole solve crosses it; forcing rows_T above m prices every iteration row-wise."""
+    from tests.lp_families import log3, make_lp
+
+    lps = []
+    for seed in range(9300, 9340):
+        a, b, c = make_lp(seed, seed % 3, 2, 70)
+        lps.append((seed, core.CoreLP.from_inequality_form(a, b, c)))
+    a, b, c = core.gen_dense_lp(seed=9399, m=192, n_struct=448)
+    lps.append((9399, core.CoreLP.from_inequality_form(a, b, c)))
+    compared = 0
+    for seed, lp in lps:
+        runs = {}
+        for mode in ("rows", "columns", "rows_always"):
+            monkeypatch.delenv("DZG_PRICE_ROWS", raising=False)
+            monkeypatch.delenv("DZG_PRICE_ROWS_T", raising=False)
+            if mode == "columns":
+                monkeypatch.setenv("DZG_PRICE_ROWS", "0")
+            if mode == "rows_always":
+                monkeypatch.setenv("DZG_PRICE_ROWS_T", "1000000")
+            runs[mode] = core.solve(lp, numerics=core.FAST, max_iter=20000, poll_interval=16)
+        want = runs["columns"]
+        for mode in ("rows", "rows_always"):
+            got = runs[mode]
+            if seed % 3 == 0: # continuous data (the integer / 0-1 families pivot on exact ties and
+                # zeros, where the monitor's relative measure has no scale in either mode)
+                assert got.max_pivot_error < 1e-8, (seed, mode, got.max_pivot_error)
+            if got.near_ties == 0 and want.near_ties == 0:
+                assert got.status == want.status, (seed, mode)
+                assert log3(got.pivots) == log3(want.pivots), (seed, mode)
+                compared += 1
+            if got.status == want.status == "optimal":
+                assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective)), (seed, mode)
+    assert compared >= 30
+    monkeypatch.delenv("DZG_PRICE_ROWS", raising=False)
+    monkeypatch.delenv("DZG_PRICE_ROWS_T", raising=False)
+
+
 # ------------------------------------------------------------------ three launches == seven launches
 def _same_solution(r, w):
     return (r.status == w.status and r.iterations == w.iterations and r.pivots == w.pivots
