@@ -109,14 +109,14 @@ def cpu_baseline(sample_rows: int, sample_cols: int, seed: int, pivots: int, row
     return out
 
 
-def _run_in_own_group(cmd, cwd, env, timeout):
+def _run_in_own_group(cmd, cwd, env, timeout, stdout=None):
     """Runs a child in its own process group and, on a timeout, ends the WHOLE group: rocprofv3
     starts the profiled program as a grandchild, which would otherwise keep the GPU busy while
     this process goes on to the timed measurement."""
     import signal
     import subprocess
 
-    proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL,
+    proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=stdout or subprocess.DEVNULL,
                             stderr=subprocess.DEVNULL, start_new_session=True)
     try:
         rc = proc.wait(timeout=timeout)
@@ -149,39 +149,49 @@ def pmc_traffic(args) -> dict | None:
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
-    per_launch = {}
+    per_pass, same_run = {}, None
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = tempfile.mkdtemp(prefix="dzg_pmc_", dir="/tmp")
             try:
+                # the SAME pivots as the timed region (warm-up included: the counters see every
+                # launch of the child), so that the bytes per pricing pass can stand beside the
+                # algorithmic bytes of the same passes -- both depend on k, which grows with the pivots
                 cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
-                       sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "20",
+                       sys.executable, os.path.abspath(__file__), "--steps", str(args.steps),
+                       "--warmup", str(args.warmup),
                        "--rows", str(args.rows), "--cols", str(args.cols), "--seed", str(args.seed),
                        "--price", args.price, "--no-cpu-baseline", "--no-pmc-traffic",
                        "--no-secondary", "--no-late"]
                 if args.sparse_per_col > 0:
                     cmd += ["--sparse-per-col", str(args.sparse_per_col)]
-                _run_in_own_group(cmd, "/tmp", dict(os.environ, TMPDIR="/tmp"), 240)
-                total, n = 0.0, 0
+                with open(os.path.join(out, "child.json"), "w") as child_out:
+                    _run_in_own_group(cmd, "/tmp", dict(os.environ, TMPDIR="/tmp"), 300, child_out)
+                with open(os.path.join(out, "child.json")) as f:
+                    child = json.loads(f.read().strip().splitlines()[-1])
+                passes = child["config"]["pivots_total"]
+                same_run = child["config"]["price_bytes_total"] / max(passes, 1)
+                total = 0.0
                 for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"),
                                       recursive=True):
                     with open(path) as f:
                         for row in csv.DictReader(f):
                             if row["Counter_Name"] == counter and "k_price_" in row["Kernel_Name"]:
                                 total += float(row["Counter_Value"])
-                                n += 1
             finally:
                 shutil.rmtree(out, ignore_errors=True)
-            if n == 0:
+            if passes <= 0:
                 return None
-            per_launch[counter] = total / n * 1024.0
+            per_pass[counter] = total / passes * 1024.0
     except Exception as exc:  # the profiler is optional: report null rather than fail the bench
         print(f"pmc traffic unavailable: {exc}", file=sys.stderr)
         return None
-    fetch = 2.0 * per_launch["FETCH_SIZE"]
-    return {"bytes_per_launch": fetch + per_launch["WRITE_SIZE"],
-            "fetch_bytes_corrected": fetch, "write_bytes": per_launch["WRITE_SIZE"],
-            "note": "rocprofv3 --pmc, separate passes; FETCH_SIZE x2 (gfx950), KiB units"}
+    fetch = 2.0 * per_pass["FETCH_SIZE"]
+    return {"bytes_per_launch": fetch + per_pass["WRITE_SIZE"],
+            "fetch_bytes_corrected": fetch, "write_bytes": per_pass["WRITE_SIZE"],
+            "algorithmic_bytes_per_launch_same_pivots": same_run,
+            "note": "rocprofv3 --pmc, separate passes of the same pivots as the timed region, warm-up "
+                    "included (all kernels of a pricing pass summed); FETCH_SIZE x2 (gfx950), KiB units"}
 
 
 SECONDARY = {"rows": 32768, "cols": 65536, "seed": 1005, "steps": 300, "warmup": 50}
@@ -206,16 +216,34 @@ PRICE_KERNELS = {"auto": "k_price_tree", "tree": "k_price_tree", "seq": "k_price
                  "wave": "k_price_wave2"}
 
 
+ROWS_T = None  # set by measure(): the compact width below which the dense pass runs row-wise
+ROWS_M = 0
+
+
 def _pricing(r0, r1, kernel: str) -> dict:
     """Roofline block of the pricing kernel between two result snapshots."""
     ms = r1.kernel_ms["price"] - r0.kernel_ms["price"]
     launches = r1.kernel_launches["price"] - r0.kernel_launches["price"]
     nbytes = r1.price_bytes - r0.price_bytes
     achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else float("nan")
-    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
-            "algorithmic_bytes_per_launch": nbytes / max(launches, 1)}
+    out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
+           "algorithmic_bytes_per_launch": nbytes / max(launches, 1)}
+    if ROWS_T is not None:
+        # dense matrix, AUTO pricing: the pass is chosen per pivot by the compact width k
+        k0, k1 = r0.dense_columns, r1.dense_columns
+        if max(k0, k1) < ROWS_T:
+            out["kernel"] = "k_price_rows<2> + k_price_rows_finish"
+            out["bytes_model"] = ("row-wise pass: 8 (k+1) ldt (rows of the row-major copy) + 16 G ldt "
+                                  "(partials of the G row groups, written and read) + 12 k + 32 q per "
+                                  "launch pair; k = %d..%d of %d rows" % (k0, k1, ROWS_M))
+        elif min(k0, k1) >= ROWS_T:
+            out["kernel"] = "k_price_tree"
+        else:
+            out["kernel"] = "k_price_rows<2> + k_price_rows_finish below k = %d, k_price_tree from there" % ROWS_T
+        out["rows_T"] = ROWS_T
+    return out
 
 
 def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
@@ -296,6 +324,14 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
     numerics = core.FAST if numerics_name == "fast" else core.STRICT
     # (one GPU, FAST: the sparse-basis path prices over the live entries of a column only;
     # DZG_SP_PRICE_FULL=1 brings the full pass back for comparison)
+    # dense, AUTO pricing: row-wise while k < rows_T (csrc/k_price_kernels.h), column-wise beyond
+    rows_T = int(0.93 * rows * cols / (rows + cols))
+    if os.environ.get("DZG_PRICE_ROWS_T"):
+        rows_T = int(os.environ["DZG_PRICE_ROWS_T"])
+    rows_on = (sparse_per_col <= 0 and numerics_name == "fast" and price_name == "auto"
+               and os.environ.get("DZG_PRICE_ROWS", "1") != "0")
+    global ROWS_T, ROWS_M
+    ROWS_T, ROWS_M = (rows_T if rows_on else None), rows
     kernel = (("k_price_csc_tree" if os.environ.get("DZG_SP_PRICE_FULL") == "1" else "k_price_csc_rl")
               if numerics_name == "fast" and price_name != "seq"
               else "k_price_csc") if sparse_per_col > 0 else (
@@ -355,7 +391,12 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                      "value": (rb.iterations - ra.iterations) / tw if tw > 0 else float("nan"),
                      "unit": "iterations/s", "k_at_end": rb.dense_columns, "objective": rb.objective,
                      "max_pivot_error": rb.max_pivot_error, "near_ties": rb.near_ties,
-                     "refactors": rb.refactors, "chain_fallbacks": rb.chain_fallbacks}
+                     "refactors": rb.refactors, "chain_fallbacks": rb.chain_fallbacks,
+                     # the whole solve as one number: every pivot from the first over the time spent
+                     # inside dzg_solver_run (the regime blocks above are stretches of this solve)
+                     "whole_solve": {"pivots": rb.iterations, "seconds": round(rb.solve_ms / 1e3, 2),
+                                     "value": rb.iterations / (rb.solve_ms / 1e3) if rb.solve_ms > 0 else float("nan"),
+                                     "unit": "iterations/s"}}
     finally:
         solver.close()
 
@@ -381,12 +422,15 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                          f"nonzeros per column (CSC), generator G2 seed {seed}"),
             "numerics": r1.numerics,
             "price_kernel": price_name,
-            "launches_per_iteration": (8 if sparse_per_col > 0 else 7 if SEVEN_LAUNCHES else 3)
+            "launches_per_iteration": (8 if sparse_per_col > 0 else 7 if SEVEN_LAUNCHES else
+                                       4 if (rows_on and r1.dense_columns < rows_T) else 3)
             if numerics_name == "fast" else None,
             "status_after_timed_region": status,
             "requested_steps": steps,
             "k_at_start": r0.dense_columns,
             "k_at_end": r1.dense_columns,
+            "pivots_total": r1.iterations,
+            "price_bytes_total": r1.price_bytes,
             "lp_generation_s": round(t_gen, 3),
             "upload_s": round(t_up, 3),
             "max_pivot_error": r1.max_pivot_error,
@@ -428,8 +472,10 @@ def main() -> int:
     ap.add_argument("--no-mfma", action="store_true",
                     help="skip the timed refactorisation (the \"mfma\" block) after the timed regions")
     ap.add_argument("--whole-solve", action="store_true",
-                    help="after the timed regions run the solve to its end and report the stretch "
-                         "(the benchmark LP: ~515 000 pivots, ~2 minutes)")
+                    help="after the timed regions run the solve to its end and report the stretch and "
+                         "the whole solve's average (the benchmark LP: ~515 000 pivots, ~1.5 minutes); "
+                         "on by default for the default workload")
+    ap.add_argument("--no-whole-solve", action="store_true")
     ap.add_argument("--seven-launches", action="store_true",
                     help="FAST, dense, one GPU: run an iteration as the seven launches a sharded "
                          "solver uses instead of the three-launch chain (same pivots)")
@@ -484,7 +530,9 @@ def main() -> int:
     deep_pivots = args.deep_pivots if (late_pivots > 0 and args.rows == 8192 and args.cols == 16384
                                        and args.sparse_per_col == 0) else 0
     out = measure(args.rows, args.cols, args.seed, args.sparse_per_col, args.price, args.numerics,
-                  args.steps, args.warmup, late_pivots, deep_pivots, args.whole_solve,
+                  args.steps, args.warmup, late_pivots, deep_pivots,
+                  (args.whole_solve or (deep_pivots > 0 and args.numerics == "fast"))
+                  and not args.no_whole_solve,
                   mfma_block=late_pivots > 0 and not args.no_mfma)
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
     out["roofline"]["traffic_detail"] = traffic

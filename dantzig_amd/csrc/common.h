@@ -367,6 +367,7 @@ struct DzgDev {
     const double *At;    // row-major copy of the local structural block: m rows of ldt
     long long ldt;       // >= col1 - col0, a multiple of 4; the padding columns are zero
     double *ppart;       // [PR_GMAX][ldt] partial sums of the row groups
+    double *vc;          // [m] v in compact numbering (vc[c] = v[drow[c]]), written by BTRAN
     int rows_T;          // the row-wise pass prices an iteration while ctl->ncompact < rows_T
     int k_lo_hint;       // a LOWER bound of ctl->ncompact for the batch being enqueued; -1: unknown
     int k_hint;          // an UPPER BOUND of ctl->ncompact while the enqueued batch runs (the host's

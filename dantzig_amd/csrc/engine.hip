@@ -648,13 +648,17 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                 double *at = nullptr;
                 TRY(dev_alloc(s, &at, (size_t)m * (size_t)d.ldt));
                 TRY(dev_alloc(s, &d.ppart, (size_t)dzg_price_rows_groups() * (size_t)d.ldt));
+                TRY(dev_alloc(s, &d.vc, (size_t)m));
+                HIP_OK(hipMemsetAsync(d.vc, 0, sizeof(double) * (size_t)m, s->st));
                 dzg_launch_transpose_to_rows(d.A, d.lda, m, nown, at, d.ldt, s->st);
                 d.At = at;
                 // where 8 (k + 1) n_s bytes of rows meet 8 m (n_s - k) bytes of columns, less the
                 // second launch: a function of the problem's shape alone (the same on every rank)
-                d.rows_T = (int)(0.9 * (double)m * (double)ns / ((double)ns + (double)m));
+                // (0.93: tools/price_rows_bench.hip -- 0.0205 us per row of 16 384 columns + 6 us for the
+                // finishing launch against 0.0099 us per column of 8192 rows: equal at k = 5 150 of 5 461)
+                d.rows_T = (int)(0.93 * (double)m * (double)ns / ((double)ns + (double)m));
                 if (const char *t = std::getenv("DZG_PRICE_ROWS_T")) d.rows_T = std::atoi(t);
-                if (d.rows_T < 1) d.At = nullptr;
+                if (d.rows_T < 1) { d.At = nullptr; d.vc = nullptr; }
             }
         }
         dzg_launch_fast_init(d, s->st);

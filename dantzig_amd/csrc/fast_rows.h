@@ -354,8 +354,8 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
         // row-wise pass: k (+ 1) rows of the row-major copy, the groups' partial sums written and
         // read once, v's k coefficients, and the per-position part as below
         const double nrows = (double)c.ncompact + (ci < 0 ? 1.0 : 0.0); // (a leaving slack's own row)
-        double G = ceil(nrows / 16.0);
-        G = G < 1.0 ? 1.0 : (G > 32.0 ? 32.0 : G);
+        double G = ceil(((double)c.ncompact + 1.0) / 16.0);
+        G = G > 32.0 ? 32.0 : G;
         bytes += 8.0 * nrows * (double)pa.rows_ld + 16.0 * G * (double)pa.rows_ld + 12.0 * nrows +
                  32.0 * (double)q;
     } else

@@ -407,7 +407,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
     const int lcode = d.bcode[p];
     if (has_row) {
         const double base = dslot_i >= 0 ? d.binv[(long long)p * d.ldb + dslot_i] : (lcode == -1 - row ? 1.0 : 0.0);
-        d.v[row] = base - fast_btran_eta(neta, d.U, d.ldw, d.W, d.ldw, p, row);
+        const double vr = base - fast_btran_eta(neta, d.U, d.ldw, d.W, d.ldw, p, row);
+        d.v[row] = vr;
+        if (dslot_i >= 0 && d.vc) d.vc[dslot_i] = vr; // (compact copy: the row-wise pricing pass's coefficients)
     }
     if (lead) {
         ctl->xp = d.x[p];

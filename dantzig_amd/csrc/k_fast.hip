@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_fast_btran(
     const int *__restrict__ dslot, const int *__restrict__ bcode,
     const double *__restrict__ U, long long ldu, const double *__restrict__ W, long long ldw,
     const double *__restrict__ rx_r, const int *__restrict__ rx_k,
-    const double *__restrict__ rx_h, double *__restrict__ v)
+    const double *__restrict__ rx_h, double *__restrict__ v, double *__restrict__ vc)
 {
     __shared__ double s_up[R_];
     DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256) void k_fast_btran(
                                   : (bcode[p] == -1 - r ? 1.0 : 0.0);
     double acc = 0.0;
     for (int t = 0; t < neta; ++t) acc = fma(s_up[t], W[(long long)t * ldw + r], acc);
-    v[r] = base - acc;
+    const double vr = base - acc;
+    v[r] = vr;
+    if (slot >= 0 && vc) vc[slot] = vr; // (compact copy: the row-wise pricing pass's coefficients)
 }
 
 // ---------------------------------------------------------------------------------
@@ -684,7 +686,7 @@ void dzg_launch_fast_btran(const DzgDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fast_btran, dim3((d.m + 255) / 256), dim3(256), 0, st, d.ctl, d.m, d.binv,
                        d.ldb, d.dslot, d.bcode, d.U, d.ldw, d.W, d.ldw, d.rx_r, d.rx_k, d.rx_h,
-                       d.v);
+                       d.v, d.vc);
 }
 
 void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)

@@ -837,14 +837,14 @@ __global__ __launch_bounds__(256) void k_price_csc_rl(
 //      dz_j = - sum_{c < k} v[drow[c]] * At[drow[c]][j]  ( - At[rl][j], the leaving slack's row )
 //
 // i.e. (k + 1) contiguous rows streamed instead of m rows of every nonbasic column: 8 (k+1) n_s
-// bytes against 8 m (n_s - k).  Used while k < T = 0.9 m n_s / (n_s + m) (where the two byte
-// counts cross, less the second launch); beyond that the column-wise kernel takes over.  The
+// bytes against 8 m (n_s - k).  Used while k < T = 0.93 m n_s / (n_s + m) (where the two byte
+// counts cross, less the second launch and the kernels' rates); beyond that the column-wise kernel takes over.  The
 // rule is evaluated ON THE DEVICE from ctl->ncompact by all three kernels alike (rows, finish,
 // columns: the ones that do not apply return at once), so the arithmetic a pivot gets depends on
 // the state alone; the host only leaves out launches its bounds on k prove idle.
 //
 // k_price_rows: grid (column tiles of 256 * VEC, PR_GMAX row groups).  G = min(PR_GMAX,
-// ceil(rows / 16)) groups are active; group g adds rows c = g, g + G, ... in ascending order
+// ceil((k + 1) / 16)) groups are active; group g adds rows c = g, g + G, ... in ascending order
 // (16 rows = 16 x VEC x 8 B per lane in flight) and leaves its partial sums in part[g][j].
 // k_price_rows_finish: dz = -(part[0] + part[1] + ...) in group order for the nonbasic structural
 // positions, unit columns and the fused dual ratio test exactly as k_price_tree; 256 workgroups
@@ -852,11 +852,12 @@ __global__ __launch_bounds__(256) void k_price_csc_rl(
 // compact numbering only (not on the grid, the tile width or a column sharding).
 // ---------------------------------------------------------------------------------
 #define PR_GMAX 32
-#define PR_BATCH 16
-template <int VEC>
+#define PR_BATCH 16 // rows per group at least (G = ceil(rows / PR_BATCH), capped at PR_GMAX)
+#define PR_PIPE 8   // rows per register set of the streaming loop
+template <int VEC, int PIPE = PR_PIPE>
 __global__ __launch_bounds__(256) void k_price_rows(
     const DzgCtl *ctl, int rows_T, const double *__restrict__ At, long long ldt,
-    const int *__restrict__ drow, const int *__restrict__ bcode, const double *__restrict__ v,
+    const int *__restrict__ drow, const int *__restrict__ bcode, const double *__restrict__ vc,
     double *__restrict__ part)
 {
     typedef double vec_t __attribute__((ext_vector_type(2)));
@@ -864,12 +865,14 @@ __global__ __launch_bounds__(256) void k_price_rows(
     __shared__ double s_coef[256];
     const int status = ctl->status, k = ctl->ncompact, lp = ctl->leave_pos;
     if (status != DZG_RUNNING || k >= rows_T) return;
-    const int lcode = lp >= 0 ? bcode[lp] : 0; // < 0: a slack leaves, row -1 - lcode carries v = 1
-    const int nrows = k + (lcode < 0 ? 1 : 0);
-    int G = (nrows + PR_BATCH - 1) / PR_BATCH;
-    G = G < 1 ? 1 : (G > PR_GMAX ? PR_GMAX : G);
+    // (the group count follows k alone, so that it -- and with it which rows are this workgroup's --
+    // is known after the first trip; the leaving variable's code arrives beside the row list)
+    int G = (k + 1 + PR_BATCH - 1) / PR_BATCH;
+    G = G > (int)gridDim.y ? (int)gridDim.y : G; // (gridDim.y = the finish kernel's gmax)
     const int g = blockIdx.y;
     if (g >= G) return;
+    const int lcode = lp >= 0 ? bcode[lp] : 0; // < 0: a slack leaves, row -1 - lcode carries v = 1
+    const int nrows = k + (lcode < 0 ? 1 : 0);
     const long long j0 = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     const bool live = j0 < ldt; // (ldt is a multiple of VEC)
     const double *col = At + (live ? j0 : 0);
@@ -879,32 +882,69 @@ __global__ __launch_bounds__(256) void k_price_rows(
     for (int cbase = g; cbase < nrows; cbase += 256 * G) { // block-uniform
         __syncthreads();
         const int c = cbase + (int)threadIdx.x * G;
-        if (c < nrows) {
+        if (c < nrows) { // (BTRAN left v in compact numbering; the leaving slack's own entry is 1)
             const int row = c < k ? drow[c] : -1 - lcode;
             s_off[threadIdx.x] = (long long)row * ldt;
-            s_coef[threadIdx.x] = v[row];
+            s_coef[threadIdx.x] = c < k ? vc[c] : 1.0;
         }
         __syncthreads();
         const int left = (nrows - cbase + G - 1) / G;
         const int n = left < 256 ? left : 256;
-        for (int i0 = 0; i0 < n; i0 += PR_BATCH) {
-            vec_t reg[PR_BATCH][VEC / 2];
+        // Full batches of PIPE rows, two register sets: the loads of batch b + 1 leave before
+        // batch b is added (no branch between a load and its use, so the waits count exactly); the
+        // rows are added in ascending order whatever the batching.  Then the guarded tail.
+        const int bfull = n / PIPE;
+        vec_t ra[PIPE][VEC / 2], rb[PIPE][VEC / 2];
+#define PR_LOAD(B, REG)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < PIPE; ++u) {                                            \
+        const double *src = col + s_off[(B) * PIPE + u];                                          \
+        _Pragma("unroll") for (int h = 0; h < VEC / 2; ++h)                                          \
+            REG[u][h] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(src) + h);        \
+    }
+#define PR_FMA(B, REG)                                                                               \
+    _Pragma("unroll") for (int u = 0; u < PIPE; ++u) {                                            \
+        const double cf = s_coef[(B) * PIPE + u];                                                 \
+        _Pragma("unroll") for (int h = 0; h < VEC / 2; ++h) {                                        \
+            acc[2 * h] = fma(cf, REG[u][h].x, acc[2 * h]);                                           \
+            acc[2 * h + 1] = fma(cf, REG[u][h].y, acc[2 * h + 1]);                                   \
+        }                                                                                            \
+    }
+        int bi = 0;
+        if (bfull > 0) { PR_LOAD(0, ra) }
+        while (bi + 2 < bfull) {
+            PR_LOAD(bi + 1, rb)
+            PR_FMA(bi, ra)
+            PR_LOAD(bi + 2, ra)
+            PR_FMA(bi + 1, rb)
+            bi += 2;
+        }
+        if (bfull - bi == 2) {
+            PR_LOAD(bi + 1, rb)
+            PR_FMA(bi, ra)
+            PR_FMA(bi + 1, rb)
+        } else if (bfull - bi == 1) {
+            PR_FMA(bi, ra)
+        }
+#undef PR_LOAD
+#undef PR_FMA
+        {
+            const int i0 = bfull * PIPE; // the tail: fewer than PIPE rows
 #pragma unroll
-            for (int u = 0; u < PR_BATCH; ++u)
+            for (int u = 0; u < PIPE; ++u)
                 if (i0 + u < n) {
                     const double *src = col + s_off[i0 + u];
 #pragma unroll
                     for (int h = 0; h < VEC / 2; ++h)
-                        reg[u][h] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(src) + h);
+                        ra[u][h] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(src) + h);
                 }
 #pragma unroll
-            for (int u = 0; u < PR_BATCH; ++u)
+            for (int u = 0; u < PIPE; ++u)
                 if (i0 + u < n) {
                     const double cf = s_coef[i0 + u];
 #pragma unroll
                     for (int h = 0; h < VEC / 2; ++h) {
-                        acc[2 * h] = fma(cf, reg[u][h].x, acc[2 * h]);
-                        acc[2 * h + 1] = fma(cf, reg[u][h].y, acc[2 * h + 1]);
+                        acc[2 * h] = fma(cf, ra[u][h].x, acc[2 * h]);
+                        acc[2 * h + 1] = fma(cf, ra[u][h].y, acc[2 * h + 1]);
                     }
                 }
         }
@@ -921,7 +961,7 @@ __global__ __launch_bounds__(256) void k_price_rows_finish(
     const int *__restrict__ plist, const int *__restrict__ pcode, const int *__restrict__ nbcode,
     const int *__restrict__ bcode, int col0, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
-    int *__restrict__ rz_k, double *__restrict__ rz_h)
+    int *__restrict__ rz_k, double *__restrict__ rz_h, int gmax)
 {
     // first trip, side by side: the control block, this thread's position (unit columns) and its
     // first list entry (plist / pcode hold q entries; those beyond nb_struct are stale and only
@@ -934,14 +974,12 @@ __global__ __launch_bounds__(256) void k_price_rows_finish(
         pos0 = plist[spos];
         code0 = pcode[spos];
     }
-    const int status = ctl->status, k = ctl->ncompact, lp = ctl->leave_pos;
+    const int status = ctl->status, k = ctl->ncompact;
     const int count = (int)ctl->nb_struct;
     const double mu = ctl->mu, tau = ctl->tau;
     if (status != DZG_RUNNING || k >= rows_T) return;
-    const int lcode = lp >= 0 ? bcode[lp] : 0;
-    const int nrows = k + (lcode < 0 ? 1 : 0);
-    int G = (nrows + PR_BATCH - 1) / PR_BATCH;
-    G = G < 1 ? 1 : (G > PR_GMAX ? PR_GMAX : G);
+    int G = (k + 1 + PR_BATCH - 1) / PR_BATCH; // (as k_price_rows)
+    G = G > gmax ? gmax : G;
     DzgCand2 best = dzg_cand2_none();
     double sv = 0.0, sz = 0.0, szb = 0.0;
     if (scode < 0) {
