@@ -293,6 +293,13 @@ void dzg_lu_layout(int n, DzgLu *w); // fills n, ldw, nparts
 // Host-side launch wrappers (defined in the .hip files, called by engine.hip).
 // All take the stream; all kernels early-out unless ctl->status == DZG_RUNNING.
 // ---------------------------------------------------------------------------------
+// one live entry of a column's list (k_price_csc_rl)
+struct __attribute__((aligned(16))) DzgLiveEntry {
+    int row;
+    int pad_;
+    double val;
+};
+
 struct DzgDev {
     // problem
     int m, q, n, ns;
@@ -352,8 +359,8 @@ struct DzgDev {
     // live entries of every structural column (rows of R: the rows whose slack is nonbasic), in the
     // column's CSC slice; NULL: not kept (price_kernel = SEQ, DZG_SP_PRICE_FULL=1)
     int *lcnt;             // [ns]  live entries of column j ...
-    int *lrow;             // [nnz] ... their rows, at cptr[j] + i, in the order the rows joined R
-    double *lval;          // [nnz] ... and values
+    DzgLiveEntry *lent;    // [nnz] ... row and value of each (16 bytes: one load, one cache line
+                           //       for a short list), at cptr[j] + i, in the order the rows joined R
     unsigned long long *rl_work; // [DZG_PRICE_CSC_BLOCKS] entries k_price_csc_rl walked, per workgroup
     // strict numerics
     DzgLu lu;

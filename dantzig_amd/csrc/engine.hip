@@ -434,8 +434,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             const char *full = std::getenv("DZG_SP_PRICE_FULL");
             if (o.price_kernel != DZG_PRICE_SEQ && !(full && full[0] == '1')) {
                 TRY(dev_alloc(s, &d.lcnt, (size_t)(ns ? ns : 1)));
-                TRY(dev_alloc(s, &d.lrow, ri.size() + 1));
-                TRY(dev_alloc(s, &d.lval, cv.size() + 1));
+                TRY(dev_alloc(s, &d.lent, ri.size() + 1));
                 TRY(dev_alloc(s, &d.rl_work, (size_t)DZG_RL_WORK_SLOTS));
                 HIP_OK(hipMemsetAsync(d.rl_work, 0, sizeof(unsigned long long) * DZG_RL_WORK_SLOTS, s->st));
             }
@@ -1460,13 +1459,13 @@ extern "C" int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries)
     HIP_OK(hipMemcpy(dslot.data(), d.dslot, sizeof(int) * m, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(lcnt.data(), d.lcnt, sizeof(int) * ns, hipMemcpyDeviceToHost));
     const size_t nnz = (size_t)cp[ns];
-    std::vector<int> ri(nnz + 1), lrow(nnz + 1);
-    std::vector<double> cv(nnz + 1), lval(nnz + 1);
+    std::vector<int> ri(nnz + 1);
+    std::vector<double> cv(nnz + 1);
+    std::vector<DzgLiveEntry> lent(nnz + 1);
     if (nnz) {
         HIP_OK(hipMemcpy(ri.data(), d.ridx, sizeof(int) * nnz, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(cv.data(), d.cval, sizeof(double) * nnz, hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(lrow.data(), d.lrow, sizeof(int) * nnz, hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(lval.data(), d.lval, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(lent.data(), d.lent, sizeof(DzgLiveEntry) * nnz, hipMemcpyDeviceToHost));
     }
     int64_t bad = 0, total = 0;
     std::vector<std::pair<int, double>> want, got;
@@ -1481,7 +1480,7 @@ extern "C" int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries)
             continue;
         }
         for (int i = 0; i < lcnt[j]; ++i)
-            got.emplace_back(lrow[(size_t)cp[j] + (size_t)i], lval[(size_t)cp[j] + (size_t)i]);
+            got.emplace_back(lent[(size_t)cp[j] + (size_t)i].row, lent[(size_t)cp[j] + (size_t)i].val);
         std::sort(got.begin(), got.end());
         std::sort(want.begin(), want.end());
         if (got != want) ++bad;

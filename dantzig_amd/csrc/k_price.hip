@@ -131,7 +131,7 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
         if (d.spb && d.lcnt && kernel != DZG_PRICE_SEQ) { // sparse basis: the live entries only
             if (d.q > 0)
                 hipLaunchKernelGGL(k_price_csc_rl, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl,
-                                   d.cptr, d.lcnt, d.lrow, d.lval, d.q, d.plist, d.pcode, d.nbcode, d.v,
+                                   d.cptr, d.lcnt, d.lent, d.q, d.plist, d.pcode, d.nbcode, d.v,
                                    d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, d.rl_work);
             return;
         }

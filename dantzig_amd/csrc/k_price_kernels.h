@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void k_price_csc_tree(
 // k_price_csc_rl: FAST pricing of the sparse-basis path (k_sparse.hip) over the LIVE entries only.
 // v = row p of B^-1 in row coordinates is zero outside R (the k rows whose slack is nonbasic) and
 // the leaving slack's own row, so a column's sum only needs its entries in those rows.  Every
-// column keeps them as a list in its own CSC slice (lcnt / lrow / lval: k_sp_btran appends the row
+// column keeps them as a list in its own CSC slice (lcnt / lent: k_sp_btran appends the row
 // that is about to join R before this launch, k_sp_pivot removes the row that left), and the pass
 // walks nnz * k / m entries instead of nnz: 1 in 50 at k = 1 000 of config 4, where the full pass
 // (k_price_csc_tree) spent 35 of a pivot's 100 us gathering zeros of v.  Same lane layout as the
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void k_price_csc_tree(
 #define RL_LPC 4 // lanes per column: 2048 x 256 / 4 = 131 072 columns in one pass
 __global__ __launch_bounds__(256) void k_price_csc_rl(
     const DzgCtl *ctl, const long long *__restrict__ cptr, const int *__restrict__ lcnt,
-    const int *__restrict__ lrow, const double *__restrict__ lval, int q,
+    const DzgLiveEntry *__restrict__ lent, int q,
     const int *__restrict__ plist, const int *__restrict__ pcode, const int *__restrict__ nbcode,
     const double *__restrict__ v, double *__restrict__ dz, const double *__restrict__ z,
     const double *__restrict__ zbar, double *__restrict__ rz_r, int *__restrict__ rz_k,
@@ -784,12 +784,14 @@ __global__ __launch_bounds__(256) void k_price_csc_rl(
         double a0 = 0.0, a1 = 0.0; // two independent chains per lane
         long long e = e0 + sub;
         for (; e + RL_LPC < e1; e += 2 * RL_LPC) {
-            const int r0 = lrow[e], r1 = lrow[e + RL_LPC];
-            const double c0 = lval[e], c1 = lval[e + RL_LPC];
-            a0 = fma(c0, v[r0], a0);
-            a1 = fma(c1, v[r1], a1);
+            const DzgLiveEntry n0 = lent[e], n1 = lent[e + RL_LPC];
+            a0 = fma(n0.val, v[n0.row], a0);
+            a1 = fma(n1.val, v[n1.row], a1);
         }
-        if (e < e1) a0 = fma(lval[e], v[lrow[e]], a0);
+        if (e < e1) {
+            const DzgLiveEntry n0 = lent[e];
+            a0 = fma(n0.val, v[n0.row], a0);
+        }
         double acc = a0 + a1;
 #pragma unroll
         for (int off = RL_LPC / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DZG_WAVE);

@@ -346,8 +346,7 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     const int *__restrict__ drow, const int *__restrict__ dslot,
     const double *__restrict__ rx_r, const int *__restrict__ rx_k,
     const double *__restrict__ rx_h, double *__restrict__ v, const long long *__restrict__ cptr,
-    const int *__restrict__ cidx, const double *__restrict__ rval, int *lcnt, int *lrow,
-    double *lval)
+    const int *__restrict__ cidx, const double *__restrict__ rval, int *lcnt, DzgLiveEntry *lent)
 {
     __shared__ int s_b[SP_LCAP];
     __shared__ double s_coef[SP_LCAP];
@@ -379,8 +378,11 @@ __global__ __launch_bounds__(256) void k_sp_btran(
         for (long long e = rptr[rl] + tid; e < rptr[rl + 1]; e += blockDim.x) {
             const int col = cidx[e];
             const long long at = cptr[col] + lcnt[col];
-            lrow[at] = rl;
-            lval[at] = rval[e];
+            DzgLiveEntry en;
+            en.row = rl;
+            en.pad_ = 0;
+            en.val = rval[e];
+            lent[at] = en;
             lcnt[col] += 1;
         }
     // rows outside R: zero, except the leaving slack's own row
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
     const double *__restrict__ cval, const long long *__restrict__ rptr, int *bcnt, int *bcol,
     double *bval, int *log_kind, int *log_enter, int *log_leave, double *log_mu,
     double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode,
-    const int *__restrict__ cidx, int *lcnt, int *lrow, double *lval)
+    const int *__restrict__ cidx, int *lcnt, DzgLiveEntry *lent)
 {
     __shared__ int s_ok, s_ci, s_cj;
     const DzgCtl c = *ctl;
@@ -677,9 +679,8 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
             const long long base = cptr[col];
             const int n = lcnt[col];
             for (int i = 0; i < n; ++i)
-                if (lrow[base + i] == re) {
-                    lrow[base + i] = lrow[base + n - 1];
-                    lval[base + i] = lval[base + n - 1];
+                if (lent[base + i].row == re) {
+                    lent[base + i] = lent[base + n - 1];
                     break;
                 }
             lcnt[col] = n - 1;
@@ -946,15 +947,18 @@ __global__ __launch_bounds__(256) void k_sp_rlists(int ns, const long long *__re
                                                    const int *__restrict__ ridx,
                                                    const double *__restrict__ cval,
                                                    const int *__restrict__ dslot, int *lcnt,
-                                                   int *lrow, double *lval)
+                                                   DzgLiveEntry *lent)
 {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ns; j += gridDim.x * blockDim.x) {
         const long long e0 = cptr[j];
         int n = 0;
         for (long long e = e0; e < cptr[j + 1]; ++e)
             if (dslot[ridx[e]] >= 0) {
-                lrow[e0 + n] = ridx[e];
-                lval[e0 + n] = cval[e];
+                DzgLiveEntry en;
+                en.row = ridx[e];
+                en.pad_ = 0;
+                en.val = cval[e];
+                lent[e0 + n] = en;
                 ++n;
             }
         lcnt[j] = n;
@@ -986,7 +990,7 @@ void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st)
                        d.bslot, d.bcnt, d.bcol, d.bval);
     if (d.lcnt)
         hipLaunchKernelGGL(k_sp_rlists, dim3(sp_grid(d.ns)), dim3(256), 0, st, d.ns, d.cptr, d.ridx,
-                           d.cval, d.dslot, d.lcnt, d.lrow, d.lval);
+                           d.cval, d.dslot, d.lcnt, d.lent);
 }
 
 // need_kind = PRIMAL: the head of the iteration (status + primal FTRAN); DUAL: after pricing
@@ -1015,7 +1019,7 @@ void dzg_launch_sp_btran(const DzgDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_sp_btran, dim3(sp_grid(d.m)), dim3(256), 0, st, d.ctl, d.m, nparts, d.rptr,
                        d.bcnt, d.bcol, d.bval, d.bslot, d.sslot, d.bcode, d.binv, d.ldb, d.U,
                        d.ldw, d.W, d.ldw, d.drow, d.dslot, d.rx_r, d.rx_k, d.rx_h, d.v, d.cptr, d.cidx,
-                       d.rval, d.lcnt, d.lrow, d.lval);
+                       d.rval, d.lcnt, d.lent);
 }
 
 void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st)
@@ -1024,7 +1028,7 @@ void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st)
                        d.zbar, d.dx, d.dz, d.basis, d.nonbasis, d.var_col, d.drow, d.dslot, d.sslot,
                        d.spos, d.bslot, d.rowpos, d.plist, d.pslot, d.cptr, d.ridx, d.cval, d.rptr, d.bcnt,
                        d.bcol, d.bval, d.log_kind, d.log_enter, d.log_leave, d.log_mu, d.log_margin,
-                       d.log_cap, d.bcode, d.nbcode, d.pcode, d.cidx, d.lcnt, d.lrow, d.lval);
+                       d.log_cap, d.bcode, d.nbcode, d.pcode, d.cidx, d.lcnt, d.lent);
 }
 
 void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st)

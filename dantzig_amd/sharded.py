@@ -228,7 +228,10 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
             "max_pivot_error": res.max_pivot_error,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "pricing kernel of rank 0 (its column block only)",
+            "bound": "hbm",
+            "kernel": "pricing pass of rank 0 over its column block: row-wise (k_price_rows + "
+                      "k_price_rows_finish) while k < 0.93 m n_s / (n_s + m), k_price_tree beyond; "
+                      "k = %d at the end of the timed region" % res.dense_columns,
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": None, "avg_launch_us": 1e3 * d_ms / max(d_launch, 1),
         },
