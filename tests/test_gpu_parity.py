@@ -1117,6 +1117,16 @@ def test_row_wise_pricing_agrees_with_the_column_pass(core, monkeypatch):
             if got.status == want.status == "optimal":
                 assert abs(got.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective)), (seed, mode)
     assert compared >= 30
+    # several column tiles and up to a dozen row groups: 512 x 2048, the first 3000 pivots
+    a, b, c = core.gen_dense_lp(seed=9398, m=512, n_struct=2048)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    monkeypatch.delenv("DZG_PRICE_ROWS", raising=False)
+    monkeypatch.delenv("DZG_PRICE_ROWS_T", raising=False)
+    rows = core.solve(lp, numerics=core.FAST, max_iter=3000, poll_interval=50)
+    monkeypatch.setenv("DZG_PRICE_ROWS", "0")
+    cols = core.solve(lp, numerics=core.FAST, max_iter=3000, poll_interval=50)
+    assert rows.dense_columns > 150 and rows.max_pivot_error < 1e-9
+    assert log3(rows.pivots) == log3(cols.pivots)
     monkeypatch.delenv("DZG_PRICE_ROWS", raising=False)
     monkeypatch.delenv("DZG_PRICE_ROWS_T", raising=False)
 
