@@ -644,12 +644,20 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             if (!d.csc && o.price_kernel == DZG_PRICE_AUTO && m > 0 && nown > 0 && ns > 0 &&
                 !(rows_env && rows_env[0] == '0')) {
                 d.ldt = ((long long)nown + 3) / 4 * 4;
-                double *at = nullptr;
-                TRY(dev_alloc(s, &at, (size_t)m * (size_t)d.ldt));
-                TRY(dev_alloc(s, &d.ppart, (size_t)dzg_price_rows_groups() * (size_t)d.ldt));
-                TRY(dev_alloc(s, &d.vc, (size_t)m));
-                HIP_OK(hipMemsetAsync(d.vc, 0, sizeof(double) * (size_t)m, s->st));
-                dzg_launch_transpose_to_rows(d.A, d.lda, m, nown, at, d.ldt, s->st);
+                // (the copy doubles the matrix: a device that cannot hold it prices column-wise)
+                void *at_mem = nullptr;
+                if (hipMalloc(&at_mem, sizeof(double) * (size_t)m * (size_t)d.ldt) != hipSuccess) {
+                    (void)hipGetLastError();
+                    at_mem = nullptr;
+                }
+                double *at = static_cast<double *>(at_mem);
+                if (at) {
+                    s->allocs.push_back(at_mem);
+                    TRY(dev_alloc(s, &d.ppart, (size_t)dzg_price_rows_groups() * (size_t)d.ldt));
+                    TRY(dev_alloc(s, &d.vc, (size_t)m));
+                    HIP_OK(hipMemsetAsync(d.vc, 0, sizeof(double) * (size_t)m, s->st));
+                    dzg_launch_transpose_to_rows(d.A, d.lda, m, nown, at, d.ldt, s->st);
+                }
                 d.At = at;
                 // where 8 (k + 1) n_s bytes of rows meet 8 m (n_s - k) bytes of columns, less the
                 // second launch: a function of the problem's shape alone (the same on every rank)
