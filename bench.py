@@ -536,6 +536,19 @@ def main() -> int:
                   mfma_block=late_pivots > 0 and not args.no_mfma)
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
     out["roofline"]["traffic_detail"] = traffic
+    if ROWS_T is not None:
+        # the pass moves 8 (k+1) n_s bytes: launch-bound while k is a few hundred, a stream later in
+        # the same solve -- the fractions measured there, side by side (blocks "late" and "deep")
+        regimes = {"k=%d..%d (timed region)" % (out["config"]["k_at_start"], out["config"]["k_at_end"]):
+                   out["roofline"]["frac"]}
+        for name in ("late", "deep"):
+            blk = out.get(name)
+            if blk and "roofline" in blk:
+                regimes["k=%d..%d (%s)" % (blk["k_at_start"], blk["k_at_end"], name)] = blk["roofline"]["frac"]
+        out["roofline"]["frac_by_regime"] = regimes
+        out["roofline"]["frac_note"] = ("the column-wise kernel (k >= rows_T, and every pivot before the "
+                                        "row-wise pass existed) streams at 0.80-0.83 of the HBM peak "
+                                        "(profiles/r03_bench_before_row_pricing.json)")
     if under_profiler():
         out["config"]["under_profiler"] = True
     if secondary_wanted(args):

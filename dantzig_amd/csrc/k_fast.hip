@@ -502,9 +502,14 @@ __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int 
     }
 }
 
-__global__ void k_fast_flush_done(DzgCtl *ctl)
+// kcap: the compact width the flush's grid covered (the host's bound on k for the batch, k_hint).
+// A wider inverse would have been flushed in part only: loud, not silent.
+__global__ void k_fast_flush_done(DzgCtl *ctl, int kcap)
 {
-    if (ctl->neta >= R_) ctl->neta = 0;
+    if (ctl->neta >= R_) {
+        if (ctl->ncompact > kcap && ctl->status == DZG_RUNNING) ctl->status = DZG_PANIC;
+        ctl->neta = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, int *dslot,
@@ -710,7 +715,7 @@ void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
     else
         hipLaunchKernelGGL(k_fast_flush_mfma<true>, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
                            d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
-    hipLaunchKernelGGL(k_fast_flush_done, dim3(1), dim3(1), 0, st, d.ctl);
+    hipLaunchKernelGGL(k_fast_flush_done, dim3(1), dim3(1), 0, st, d.ctl, ((kmax + 63) / 64) * 64);
 }
 
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st)

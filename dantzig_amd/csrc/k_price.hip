@@ -153,14 +153,18 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
         rows_T = d.rows_T;
         const bool rows_possible = d.k_lo_hint < 0 || d.k_lo_hint < rows_T;
         const bool cols_possible = d.k_hint <= 0 || d.k_hint >= rows_T;
+        // (whichever pass is left out, the other one prices unconditionally: a bound the host got
+        // wrong would cost speed, never a pass)
+        const int rows_rule = cols_possible ? rows_T : 0x7fffffff;
+        if (!rows_possible) rows_T = 0;
         if (rows_possible) {
             // (two columns per lane, 512 per workgroup: 83 us for k = 4 049 rows of 16 384 columns
             // against 92 with four -- tools/price_rows_bench.hip, profiles/r03_price_rows_microbench.txt)
             hipLaunchKernelGGL((k_price_rows<2>), dim3((unsigned)((d.ldt + 511) / 512), PR_GMAX),
-                               dim3(256), 0, st, d.ctl, rows_T, d.At, d.ldt, d.drow, d.bcode, d.vc,
+                               dim3(256), 0, st, d.ctl, rows_rule, d.At, d.ldt, d.drow, d.bcode, d.vc,
                                d.ppart);
             hipLaunchKernelGGL(k_price_rows_finish, dim3(DZG_PRICE_TREE_BLOCKS), dim3(256), 0, st,
-                               d.ctl, rows_T, d.ppart, d.ldt, d.q, d.plist, d.pcode, d.nbcode, d.bcode,
+                               d.ctl, rows_rule, d.ppart, d.ldt, d.q, d.plist, d.pcode, d.nbcode, d.bcode,
                                d.col0, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, PR_GMAX);
         }
         if (!cols_possible) return;

@@ -883,9 +883,14 @@ __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double
         }
 }
 
-__global__ void k_sp_flush_done(DzgCtl *ctl)
+// kcap: the block width the flush's grid covered (the host's bound on k for the batch, k_hint).
+// A wider block would have been flushed in part only: loud, not silent.
+__global__ void k_sp_flush_done(DzgCtl *ctl, int kcap)
 {
-    if (ctl->status == DZG_RUNNING && ctl->neta >= R_) ctl->neta = 0;
+    if (ctl->status == DZG_RUNNING && ctl->neta >= R_) {
+        if (ctl->ncompact > kcap) ctl->status = DZG_PANIC;
+        ctl->neta = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1044,7 +1049,7 @@ void dzg_launch_sp_flush(const DzgDev &d, hipStream_t st)
     const int kmax = d.k_hint > 0 && d.k_hint < d.m ? d.k_hint : d.m;
     hipLaunchKernelGGL(k_sp_flush_mfma, dim3((kmax + 63) / 64, (kmax + 63) / 64), dim3(256), 0, st,
                        d.ctl, d.binv, d.ldb, d.U, d.ldw, d.W, d.ldw);
-    hipLaunchKernelGGL(k_sp_flush_done, dim3(1), dim3(1), 0, st, d.ctl);
+    hipLaunchKernelGGL(k_sp_flush_done, dim3(1), dim3(1), 0, st, d.ctl, ((kmax + 63) / 64) * 64);
 }
 
 void dzg_launch_sp_ref_copy(const DzgDev &d, int k, const double *Xinv, long long ldx, hipStream_t st)
