@@ -681,9 +681,9 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
             for (int i = 0; i < n; ++i)
                 if (lent[base + i].row == re) {
                     lent[base + i] = lent[base + n - 1];
+                    lcnt[col] = n - 1;
                     break;
                 }
-            lcnt[col] = n - 1;
         }
     }
 }
