@@ -841,8 +841,8 @@ __global__ __launch_bounds__(256) void k_sp_flush_mfma(const DzgCtl *ctl, double
     const int li = lane & 15, lk = lane >> 4;
     // Everything the workgroup needs leaves in ONE trip: the 64 x 64 tile of W the four waves share
     // (through LDS), this wave's 16 x 64 strip of U^T and its 16 x 64 strip of X.  (Step by step --
-    // a load, a wait, four MFMAs, sixteen times over -- a flush took 537 us at k = 4 126 where X
-    // streams in 50.)  Rows / columns beyond k are clamped to k - 1: a row of the product depends
+    // a load, a wait, four MFMAs, sixteen times over -- a flush took 131 us at k = 1 175, 9 us
+    // this way.)  Rows / columns beyond k are clamped to k - 1: a row of the product depends
     // on its own row of U only, a column on its own column of W, and neither is stored.
     double wreg[16];
     {
