@@ -1127,6 +1127,18 @@ def test_row_wise_pricing_agrees_with_the_column_pass(core, monkeypatch):
     cols = core.solve(lp, numerics=core.FAST, max_iter=3000, poll_interval=50)
     assert rows.dense_columns > 150 and rows.max_pivot_error < 1e-9
     assert log3(rows.pivots) == log3(cols.pivots)
+    # more nonbasic positions than the finishing launch has threads (65 536): 40 x 70 000
+    a, b, c = core.gen_dense_lp(seed=9397, m=40, n_struct=70000)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    monkeypatch.delenv("DZG_PRICE_ROWS", raising=False)
+    monkeypatch.setenv("DZG_PRICE_ROWS_T", "1000000")
+    rows = core.solve(lp, numerics=core.FAST, max_iter=400, poll_interval=50)
+    monkeypatch.delenv("DZG_PRICE_ROWS_T", raising=False)
+    monkeypatch.setenv("DZG_PRICE_ROWS", "0")
+    cols = core.solve(lp, numerics=core.FAST, max_iter=400, poll_interval=50)
+    assert rows.status == cols.status and rows.max_pivot_error < 1e-9
+    if rows.near_ties == 0 and cols.near_ties == 0:
+        assert log3(rows.pivots) == log3(cols.pivots)
     monkeypatch.delenv("DZG_PRICE_ROWS", raising=False)
     monkeypatch.delenv("DZG_PRICE_ROWS_T", raising=False)
 
