@@ -1552,14 +1552,14 @@ extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
         res->kernel_launches[c] = s->kernel_launches[c];
     }
     res->price_bytes = s->h_ctl->price_bytes;
-    if (s->d.rl_work) { // live-entry pricing counts the entries it walked itself: 12 bytes each
+    if (s->d.rl_work) { // live-entry pricing counts the entries it walked itself: 16-byte records
         std::vector<unsigned long long> w(DZG_RL_WORK_SLOTS);
         HIP_OK(hipMemcpyAsync(w.data(), s->d.rl_work, sizeof(unsigned long long) * w.size(),
                               hipMemcpyDeviceToHost, s->st));
         HIP_OK(hipStreamSynchronize(s->st));
         unsigned long long walked = 0;
         for (unsigned long long x : w) walked += x;
-        res->price_bytes += 12.0 * (double)walked;
+        res->price_bytes += 16.0 * (double)walked;
     }
     res->solve_ms = s->solve_ms;
     res->max_pivot_error = s->max_err_life;

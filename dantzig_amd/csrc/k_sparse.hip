@@ -566,7 +566,7 @@ __device__ __forceinline__ int sp_pivot_books(
         log_margin[it] = c.margin;
     }
     long long ns = c.nb_struct;
-    // (live-entry pricing: the 12 bytes per walked entry are counted by the kernel itself, rl_work)
+    // (live-entry pricing: the 16 bytes per walked entry are counted by the kernel itself, rl_work)
     ctl->price_bytes = c.price_bytes +
                        (live_lists ? 20.0 * (double)ns
                                    : 12.0 * (double)c.nb_nnz + 4.0 * (double)(ns + 1)) +

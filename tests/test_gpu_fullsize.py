@@ -245,7 +245,7 @@ def test_config4_fast_run_invariants(core, sparse_lp):
     # ~2 * PER_COL4 entries each) beside its per-column and per-position constants
     per_launch = res.price_bytes / res.iterations
     assert 20 * (NS4 - 1000) + 8 * M4 + 32 * NS4 <= per_launch
-    assert per_launch <= 20 * NS4 + 8 * M4 + 32 * NS4 + 12 * 1000 * 4 * PER_COL4
+    assert per_launch <= 20 * NS4 + 8 * M4 + 32 * NS4 + 16 * 1000 * 4 * PER_COL4
     # a budgeted continuation resumes the same trajectory: same log as an uninterrupted run
     with core.Solver(lp, numerics=core.FAST, poll_interval=64) as s2:
         assert s2.run(300) == "iter_limit" and s2.run(700) == "iter_limit"
