@@ -37,7 +37,7 @@ EXPORTS = [
     "dzg_shard_run", "dzg_shard_run_lockstep", "dzg_solver_stream", "dzg_solver_refactor",
     "dzg_gen_dense_lp_block", "dzg_solver_set_profile", "dzg_kernel_neg_t_dot_csc",
     "dzg_shard_comm_size", "dzg_solver_upload_columns", "dzg_debug_hold_cus", "dzg_debug_hold_wait",
-    "dzg_core_solve_full_csc", "dzg_debug_live_lists",
+    "dzg_core_solve_full_csc", "dzg_debug_live_lists", "dzg_debug_rl_listed",
 ]
 
 

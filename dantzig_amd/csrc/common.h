@@ -40,7 +40,10 @@ struct DzgCtl {
     int use_record;      // 1: fast_pivot_books takes zr/zbar_r/dz_r instead of its local z arrays
     int del_last;        // >= 0: k_fast_update deletes a compact column of Binv0 (an entering
     int del_ce;          //       slack): column del_ce := column del_last, column del_last := 0
-    int pad2;
+    int rl_listed;       // sparse-basis live-entry lists: the row k_sp_btran has appended to its columns'
+                         // lists for a pivot that has not executed yet (-1: none).  A run that stops
+                         // between BTRAN and the pivot (DZG_NEAR_TIE in the dual ratio test) leaves
+                         // it set, and the resumed iteration does not append the row a second time
     long long nb_nnz;     // sparse mode: stored entries of the owned nonbasic structural columns
     double max_pivot_err; // FAST health: max |dx_p + dz_r| / max(|dx_p|, |dz_r|) since the last
                           // refactorisation
@@ -444,10 +447,17 @@ void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st);
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st);
 void dzg_launch_refactor_lists(const DzgDev &d, int *spos, int *scode, int *lpos, int *lrow,
                                int *counts, hipStream_t st);
-void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, double *Tri,
-                         long long ldg,
-                         int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
-                         int *singular, hipStream_t st);
+// the refactorisation in three stages (k_refactor.hip): between A and B, and between B and C, a
+// partitioned column-sharded solve sums G (k x ldg) and the block B returns (nl x ldg) over its ranks
+void dzg_launch_refactor_a(const DzgDev &d, int k, double *G, double *X, long long ldg, int *scode,
+                           int *singular, hipStream_t st);
+double *dzg_launch_refactor_b(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, double *Tri,
+                              long long ldg,
+                              int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
+                              int *singular, hipStream_t st);
+void dzg_launch_refactor_c(const DzgDev &d, int k, int nl, double *G, double *X, long long ldg,
+                           int *lpos, int *singular, hipStream_t st);
+void dzg_launch_lockstep_sum(double *const *bufs, int world, long long count, hipStream_t st);
 void dzg_launch_shard_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
 void dzg_launch_lockstep_allgather(double *const *ptrs, int world, int which, long long xstride,
                                    hipStream_t st);

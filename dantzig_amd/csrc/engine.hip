@@ -101,6 +101,10 @@ struct dzg_solver {
     int *rf_piv = nullptr, *rf_spos = nullptr, *rf_scode = nullptr, *rf_lpos = nullptr,
         *rf_lrow = nullptr, *rf_counts = nullptr, *rf_lslot = nullptr;
     long long since_refactor = 0;
+    bool pending_refactor = false; // a warm start whose basic columns are not all on this device yet
+                                   // (partitioned shards; replicate_matrix before the last upload):
+                                   // the starting basis is factorised by the first run instead
+    bool in_lockstep = false;      // inside dzg_shard_run_lockstep (the harness sums over the ranks)
     // STRICT: the O(m) launches of one basis solve, captured once and replayed (hipGraph)
     hipGraphExec_t g_solve[2] = {nullptr, nullptr}; // [0] B dx = a_j, [1] B^T v = e_p
     bool graphs_tried = false;
@@ -193,6 +197,7 @@ struct Rccl {
     int (*GetUniqueId)(NcclUniqueId *) = nullptr;
     int (*CommInitRank)(void **, int, NcclUniqueId, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -214,6 +219,7 @@ Rccl &rccl()
     r.GetUniqueId = (int (*)(NcclUniqueId *))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(void **, int, NcclUniqueId, int))dlsym(r.handle, "ncclCommInitRank");
     r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.handle, "ncclAllGather");
+    r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(r.handle, "ncclAllReduce");
     r.CommDestroy = (int (*)(void *))dlsym(r.handle, "ncclCommDestroy");
     r.CommCount = (int (*)(void *, int *))dlsym(r.handle, "ncclCommCount");
     r.GetErrorString = (const char *(*)(int))dlsym(r.handle, "ncclGetErrorString");
@@ -221,12 +227,14 @@ Rccl &rccl()
     return r;
 }
 const int kNcclFloat64 = 8;
+const int kNcclSum = 0;
 } // namespace
 
 static void shard_comm_destroy(dzg_solver *s);
 static int shard_buffers(dzg_solver *s);
 static int refactor_now(dzg_solver *s);
 static int refactor_workspace(dzg_solver *s);
+static bool partitioned(const dzg_solver *s);
 
 // DZG_CHAIN_DEBUG=1: where workgroup 0 of the chain kernels spent its time (stderr, at destroy)
 static void chain_debug_report(dzg_solver *s)
@@ -549,6 +557,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     c0.iter_stop = o.max_iter;
     c0.enter_pos = c0.leave_pos = -1;
     c0.del_ce = c0.del_last = -1;
+    c0.rl_listed = -1;
     c0.nb_struct = nb_struct;
     c0.tie_tol = c0.tau = o.tie_tol;
     c0.margin = c0.min_margin = std::numeric_limits<double>::infinity();
@@ -564,14 +573,14 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         for (int p = 0; p < m; ++p)
             if (var_col[basis[p]] >= 0) slack_basis = false;
         if (!slack_basis) {
-            if (d.world > 1 && !(d.repl && s->cols_present == ns))
-                return fail(DZG_E_ARG, "a non-slack starting basis of a column-sharded FAST solver "
-                                       "needs the whole matrix at creation (replicate_matrix, "
-                                       "a_is_block = 0)");
+            // a column-sharded rank that does not hold every basic column yet (partitioned storage, or
+            // replicate_matrix before dzg_solver_upload_columns has run) factorises the starting
+            // basis at its first run, where the ranks can exchange their columns' shares
+            if (d.world > 1 && !(d.repl && s->cols_present == ns)) s->pending_refactor = true;
             if (o.refactor_interval == 0) o.refactor_interval = -1; // reserve the workspace
             s->opts.refactor_interval = o.refactor_interval;
         }
-        const bool needs_initial_refactor = !slack_basis;
+        const bool needs_initial_refactor = !slack_basis && !s->pending_refactor;
         // row stride: not a multiple of a large power of two, so that the first k columns of
         // consecutive rows do not all land on the same HBM channels
         d.ldb = ((long long)m + 15) / 16 * 16 + 32;
@@ -861,9 +870,6 @@ static int read_ctl(dzg_solver *s)
 static int refactor_workspace(dzg_solver *s)
 {
     if (s->rfG) return 0;
-    if (s->d.world > 1 && !s->d.repl)
-        return fail(DZG_E_ARG, "refactorisation needs every basic column on the device: a "
-                               "column-sharded solver has them with opts.replicate_matrix only");
     const size_t m = (size_t)(s->d.m ? s->d.m : 1);
     s->rf_ld = ((long long)s->d.m + 15) / 16 * 16 + 16;
     double *g = nullptr;
@@ -879,25 +885,122 @@ static int refactor_workspace(dzg_solver *s)
     return 0;
 }
 
-static int refactor_now(dzg_solver *s)
+// A rank of a PARTITIONED column-sharded solve holds its own structural columns only (a
+// replicated one holds them all, like a single GPU).
+static bool partitioned(const dzg_solver *s) { return s->d.world > 1 && !s->d.repl; }
+
+// Stage A: the basis lists, one host sync to learn k and nl, the rank's share of G = A[R, S].
+// *active = false: the solve has ended, nothing to refactorise (every rank alike).
+static int refactor_stage_a(dzg_solver *s, int counts[2], bool *active)
 {
     TRY(refactor_workspace(s));
     const DzgDev &d = s->d;
     dzg_launch_refactor_lists(d, s->rf_spos, s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_counts, s->st);
-    int counts[2] = {0, 0};
-    HIP_OK(hipMemcpyAsync(counts, s->rf_counts, sizeof(counts), hipMemcpyDeviceToHost, s->st));
+    counts[0] = counts[1] = 0;
+    HIP_OK(hipMemcpyAsync(counts, s->rf_counts, sizeof(int) * 2, hipMemcpyDeviceToHost, s->st));
     TRY(read_ctl(s));
-    if (s->h_ctl->status != DZG_RUNNING && s->h_ctl->status != DZG_ITER_LIMIT &&
-        s->h_ctl->status != DZG_NEAR_TIE)
-        return 0;
+    *active = s->h_ctl->status == DZG_RUNNING || s->h_ctl->status == DZG_ITER_LIMIT ||
+              s->h_ctl->status == DZG_NEAR_TIE;
+    if (!*active) return 0;
     if (counts[0] != s->h_ctl->ncompact)
         return fail(DZG_E_DEVICE, "refactor: structural basics != dense columns");
-    dzg_launch_refactor(d, counts[0], counts[1], s->rfG, s->rfX, s->rfPn, s->rfTri, s->rf_ld, s->rf_piv, s->rf_spos,
-                        s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_lslot, s->rf_counts + 2, s->st);
+    dzg_launch_refactor_a(d, counts[0], s->rfG, s->rfX, s->rf_ld, s->rf_scode, s->rf_counts + 2, s->st);
+    return 0;
+}
+
+// Stage B: LU, the inverse, Binv0's rows of the structural positions, the rank's share of A[L, S]
+// (*block, nl x rf_ld; nullptr: none).
+static int refactor_stage_b(dzg_solver *s, const int counts[2], double **block)
+{
+    *block = dzg_launch_refactor_b(s->d, counts[0], counts[1], s->rfG, s->rfX, s->rfPn, s->rfTri, s->rf_ld,
+                                   s->rf_piv, s->rf_spos, s->rf_scode, s->rf_lpos, s->rf_lrow, s->rf_lslot,
+                                   s->rf_counts + 2, s->st);
+    return 0;
+}
+
+// Stage C: Binv0's rows of the basic slacks, the eta file emptied, the monitor restarted.
+static int refactor_stage_c(dzg_solver *s, const int counts[2])
+{
+    dzg_launch_refactor_c(s->d, counts[0], counts[1], s->rfG, s->rfX, s->rf_ld, s->rf_lpos,
+                          s->rf_counts + 2, s->st);
     s->since_flush = 0;
     s->h_ctl->neta = 0; // the refactorisation empties the eta file (k_ref_done)
     s->since_refactor = 0;
     s->refactors += 1;
+    s->pending_refactor = false;
+    return 0;
+}
+
+// sum of a block over the ranks of the RCCL communicator, in place (a column has one owner: exact)
+static int shard_sum(dzg_solver *s, double *buf, size_t count)
+{
+    if (count == 0) return 0;
+    Rccl &r = rccl();
+    if (!s->comm || !r.ok || !r.AllReduce)
+        return fail(DZG_E_ARG, "refactorisation of a partitioned column-sharded solver needs its "
+                               "ranks' columns: dzg_shard_comm_init first (or the lockstep loop)");
+    if (r.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, s->comm, s->st) != 0)
+        return fail(DZG_E_DEVICE, "ncclAllReduce (basic columns of a refactorisation)");
+    return 0;
+}
+
+static int refactor_now(dzg_solver *s)
+{
+    if (partitioned(s) && s->in_lockstep)
+        return fail(DZG_E_ARG, "refactor: the lockstep loop refactorises its ranks together");
+    int counts[2];
+    bool active = false;
+    TRY(refactor_stage_a(s, counts, &active));
+    if (!active) return 0;
+    // (every rank of a sharded solve gets here at the same pivot count with the same k and nl: the
+    // triggers -- interval, health monitor, a pending warm start -- read replicated state only)
+    if (partitioned(s)) TRY(shard_sum(s, s->rfG, (size_t)counts[0] * (size_t)s->rf_ld));
+    double *block = nullptr;
+    TRY(refactor_stage_b(s, counts, &block));
+    if (partitioned(s) && block) TRY(shard_sum(s, block, (size_t)counts[1] * (size_t)s->rf_ld));
+    return refactor_stage_c(s, counts);
+}
+
+// All ranks of a lockstep group (one process, one device, one stream) refactorise together; the
+// sums over the ranks of a partitioned solve are one kernel each.
+static int refactor_lockstep(dzg_solver **sv, int world)
+{
+    if (!partitioned(sv[0])) {
+        for (int r = 0; r < world; ++r) TRY(refactor_now(sv[r]));
+        return 0;
+    }
+    std::vector<int> counts((size_t)2 * world, 0);
+    bool active = false;
+    for (int r = 0; r < world; ++r) {
+        bool a = false;
+        TRY(refactor_stage_a(sv[r], &counts[(size_t)2 * r], &a));
+        if (r > 0 && (a != active || counts[(size_t)2 * r] != counts[0] || counts[(size_t)2 * r + 1] != counts[1]))
+            return fail(DZG_E_DEVICE, "lockstep refactor: ranks diverged");
+        active = a;
+    }
+    if (!active) return 0;
+    hipStream_t st = sv[0]->st;
+    double **dptrs = nullptr;
+    HIP_OK(hipMalloc(&dptrs, sizeof(double *) * (size_t)world));
+    struct Free { double **p; ~Free() { hipFree(p); } } free_ptrs{dptrs};
+    std::vector<double *> ptrs((size_t)world);
+    for (int r = 0; r < world; ++r) ptrs[(size_t)r] = sv[r]->rfG;
+    HIP_OK(hipMemcpyAsync(dptrs, ptrs.data(), sizeof(double *) * (size_t)world, hipMemcpyHostToDevice, st));
+    dzg_launch_lockstep_sum(dptrs, world, (long long)counts[0] * sv[0]->rf_ld, st);
+    HIP_OK(hipStreamSynchronize(st)); // (ptrs is rewritten below)
+    bool any_block = false;
+    for (int r = 0; r < world; ++r) {
+        double *block = nullptr;
+        TRY(refactor_stage_b(sv[r], &counts[(size_t)2 * r], &block));
+        ptrs[(size_t)r] = block;
+        any_block = any_block || block;
+    }
+    if (any_block) {
+        HIP_OK(hipMemcpyAsync(dptrs, ptrs.data(), sizeof(double *) * (size_t)world, hipMemcpyHostToDevice, st));
+        dzg_launch_lockstep_sum(dptrs, world, (long long)counts[1] * sv[0]->rf_ld, st);
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    for (int r = 0; r < world; ++r) TRY(refactor_stage_c(sv[r], &counts[(size_t)2 * r]));
     return 0;
 }
 
@@ -933,36 +1036,53 @@ static int health_stop(dzg_solver *s)
 }
 
 // FAST health between batches: the pivot element computed by FTRAN and by BTRAN + pricing must
-// agree.  A drift is shed by a refactorisation (workspace reserved on first need); where that is
-// impossible -- a partitioned sharded solver, out of memory -- or does not help, the solve stops
-// with DZG_SINGULAR.  Every rank of a sharded solve sees the same max_pivot_err (replicated dx_p,
-// published dz_r) and therefore takes the same action.
+// agree.  A drift is shed by a refactorisation (workspace reserved on first need; the ranks of a
+// partitioned sharded solve exchange their basic columns for it); where that is impossible -- a
+// partitioned solver whose host drives the phases itself, out of memory -- or does not help, the
+// solve stops with DZG_SINGULAR.  Every rank of a sharded solve sees the same max_pivot_err
+// (replicated dx_p, published dz_r) and therefore takes the same action.
+enum HealthAction { HEALTH_OK = 0, HEALTH_REFACTOR, HEALTH_GIVE_UP };
+
+static bool can_refactor(const dzg_solver *s)
+{
+    return !partitioned(s) || s->comm != nullptr || s->in_lockstep;
+}
+
+static HealthAction health_decide(dzg_solver *s)
+{
+    if (!can_refactor(s)) return s->h_ctl->max_pivot_err > 1e-4 ? HEALTH_GIVE_UP : HEALTH_OK;
+    if (!(s->h_ctl->max_pivot_err > s->drift_trigger && s->since_refactor > 0)) return HEALTH_OK;
+    // a basis whose fresh inverse drifts again at once is ill-conditioned, not stale: accept a
+    // larger disagreement instead of refactorising every batch
+    const bool fresh = s->refactors > 0 && s->since_refactor <= 2ll * s->opts.poll_interval;
+    if (fresh) s->drift_trigger *= 100.0;
+    if (fresh && s->h_ctl->max_pivot_err > 1e-4) return HEALTH_GIVE_UP;
+    return HEALTH_REFACTOR;
+}
+
+static int health_give_up(dzg_solver *s, bool *stop)
+{
+    if (can_refactor(s)) s->h_ctl->max_pivot_err = 1.0;
+    TRY(health_stop(s));
+    *stop = s->h_ctl->status != DZG_RUNNING;
+    return 0;
+}
+
 static int health_check(dzg_solver *s, bool *stop)
 {
     *stop = false;
-    const bool can_refactor = s->d.world == 1 || s->d.repl;
-    if (!can_refactor) {
-        TRY(health_stop(s));
-        *stop = s->h_ctl->status != DZG_RUNNING;
-        return 0;
-    }
-    if (s->h_ctl->max_pivot_err > s->drift_trigger && s->since_refactor > 0) {
-        // a basis whose fresh inverse drifts again at once is ill-conditioned, not stale:
-        // accept a larger disagreement instead of refactorising every batch
-        const bool fresh = s->refactors > 0 && s->since_refactor <= 2ll * s->opts.poll_interval;
-        if (fresh) s->drift_trigger *= 100.0;
-        int rrc = 0;
-        if (!(fresh && s->h_ctl->max_pivot_err > 1e-4)) rrc = refactor_now(s);
+    switch (health_decide(s)) {
+    case HEALTH_OK: return 0;
+    case HEALTH_REFACTOR: {
+        const int rrc = refactor_now(s);
         // (a refactorisation that FAILED as a call -- device error, out of memory -- is that error,
         // not a singular basis)
         if (rrc == DZG_E_DEVICE || rrc == DZG_E_NOMEM) return rrc;
-        if ((fresh && s->h_ctl->max_pivot_err > 1e-4) || rrc != 0) {
-            s->h_ctl->max_pivot_err = 1.0;
-            TRY(health_stop(s));
-            *stop = true;
-        }
+        if (rrc != 0) return health_give_up(s, stop);
+        return 0;
     }
-    return 0;
+    default: return health_give_up(s, stop);
+    }
 }
 
 // Budget spent: the host ends the run itself instead of enqueueing an iteration that would only
@@ -1134,8 +1254,18 @@ static int set_budget(dzg_solver *s, int64_t max_new_iters)
         return fail(DZG_E_ARG, "replicate_matrix: " + std::to_string(s->d.ns - s->cols_present) +
                                " structural columns have not been uploaded (dzg_solver_upload_columns)");
     s->d.k_hint = s->d.k_lo_hint = 0; // (bounds of a batch that ended in an error are void)
+    if (s->pending_refactor && !partitioned(s)) TRY(refactor_now(s)); // (replicated: all columns are here now)
+    if (s->pending_refactor && !s->comm && !s->in_lockstep)
+        return fail(DZG_E_ARG, "a non-slack starting basis of a partitioned column-sharded solver is "
+                               "factorised by dzg_shard_run / dzg_shard_run_lockstep (the ranks exchange "
+                               "their basic columns): a host that drives the phases itself starts from "
+                               "the slack basis or uses replicate_matrix");
     TRY(read_ctl(s));
     DzgCtl *h = s->h_ctl;
+    // pending etas as the device counts them: a host that drives the phase entry points itself and
+    // enqueued past a stop has a flush counter ahead of the device's (the flush kernels fold a FULL
+    // file only), and would otherwise let neta reach DZG_RMAX with no flush pending
+    s->since_flush = h->neta;
     if (h->status != DZG_RUNNING && h->status != DZG_ITER_LIMIT && h->status != DZG_NEAR_TIE)
         return h->status;
     long long stop = s->opts.max_iter;
@@ -1314,6 +1444,7 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
     Rccl &r = rccl();
     const size_t n = (size_t)s->d.xstride;
     auto t0 = std::chrono::steady_clock::now();
+    if (s->pending_refactor) TRY(refactor_now(s)); // a warm start: the starting basis, all ranks together
     for (;;) {
         bool spent = false;
         TRY(budget_spent(s, &spent));
@@ -1367,9 +1498,17 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         if (!sv[r] || sv[r]->d.world != world || sv[r]->d.rank != r || sv[r]->st != sv[0]->st)
             return fail(DZG_E_ARG, "lockstep: solvers must be ranks 0..world-1 on one stream");
         TRY(shard_buffers(sv[r]));
+    }
+    struct Flag { // (the ranks refactorise together inside this call, and only here)
+        dzg_solver **sv; int world;
+        ~Flag() { for (int r = 0; r < world; ++r) sv[r]->in_lockstep = false; }
+    } flag{sv, world};
+    for (int r = 0; r < world; ++r) sv[r]->in_lockstep = true;
+    for (int r = 0; r < world; ++r) {
         const int rc0 = set_budget(sv[r], max_new_iters);
         if (rc0 != DZG_RUNNING) return rc0;
     }
+    if (sv[0]->pending_refactor) TRY(refactor_lockstep(sv, world)); // a warm start: the starting basis
     hipStream_t st = sv[0]->st;
     // the all-gather of the lockstep harness: ONE kernel copies every rank's record into every
     // rank's receive buffer (world^2 device copies per exchange would cost more than the ranks'
@@ -1392,9 +1531,8 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
         bool spent = false;
         for (int r = 0; r < world; ++r) TRY(budget_spent(sv[r], &spent));
         if (spent) break;
-        for (int r = 0; r < world; ++r)
-            if (sv[r]->opts.refactor_interval > 0 && sv[r]->since_refactor >= sv[r]->opts.refactor_interval)
-                TRY(refactor_now(sv[r]));
+        if (sv[0]->opts.refactor_interval > 0 && sv[0]->since_refactor >= sv[0]->opts.refactor_interval)
+            TRY(refactor_lockstep(sv, world));
         const int batch = batch_size(sv[0]);
         for (int r = 0; r < world; ++r) {
             sv[r]->since_flush = sv[r]->h_ctl->neta;
@@ -1422,12 +1560,25 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
             if (sv[r]->h_ctl->status != sv[0]->h_ctl->status || sv[r]->h_ctl->iter != sv[0]->h_ctl->iter)
                 return fail(DZG_E_DEVICE, "lockstep: ranks diverged");
         if (sv[0]->h_ctl->status != DZG_RUNNING) break;
-        bool stop = false;
+        // the health rule reads replicated state: every rank decides alike, the group acts together
+        HealthAction act = HEALTH_OK;
         for (int r = 0; r < world; ++r) {
-            bool one = false;
-            TRY(health_check(sv[r], &one));
-            stop = stop || one;
+            const HealthAction a = health_decide(sv[r]);
+            if (r > 0 && a != act) return fail(DZG_E_DEVICE, "lockstep: ranks diverged (health rule)");
+            act = a;
         }
+        bool stop = false;
+        if (act == HEALTH_REFACTOR) {
+            const int rrc = refactor_lockstep(sv, world);
+            if (rrc == DZG_E_DEVICE || rrc == DZG_E_NOMEM) return rrc;
+            if (rrc != 0) act = HEALTH_GIVE_UP;
+        }
+        if (act == HEALTH_GIVE_UP)
+            for (int r = 0; r < world; ++r) {
+                bool one = false;
+                TRY(health_give_up(sv[r], &one));
+                stop = stop || one;
+            }
         if (stop) break;
     }
     return sv[0]->h_ctl->status;
@@ -1459,7 +1610,10 @@ extern "C" int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries)
     const DzgDev &d = s->d;
     if (!d.spb || !d.lcnt) return fail(DZG_E_ARG, "this solver keeps no live-entry lists");
     HIP_OK(hipSetDevice(s->opts.device));
-    HIP_OK(hipStreamSynchronize(s->st));
+    TRY(read_ctl(s));
+    // a run that stopped between BTRAN and the pivot (DZG_NEAR_TIE) has that pivot's leaving slack
+    // row listed already (ctl->rl_listed): by definition part of the lists until the pivot executes
+    const int pending = s->h_ctl->rl_listed;
     const size_t ns = (size_t)d.ns, m = (size_t)d.m;
     std::vector<long long> cp(ns + 1);
     std::vector<int> dslot(m), lcnt(ns);
@@ -1481,7 +1635,8 @@ extern "C" int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries)
         want.clear();
         got.clear();
         for (long long e = cp[j]; e < cp[j + 1]; ++e)
-            if (dslot[(size_t)ri[(size_t)e]] >= 0) want.emplace_back(ri[(size_t)e], cv[(size_t)e]);
+            if (dslot[(size_t)ri[(size_t)e]] >= 0 || ri[(size_t)e] == pending)
+                want.emplace_back(ri[(size_t)e], cv[(size_t)e]);
         const long long span = cp[j + 1] - cp[j];
         if (lcnt[j] < 0 || lcnt[j] > span) {
             ++bad;
@@ -1496,6 +1651,15 @@ extern "C" int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries)
     }
     if (entries) *entries = total;
     return bad;
+}
+
+extern "C" int64_t dzg_debug_rl_listed(dzg_solver *s)
+{
+    if (!s) return fail(DZG_E_ARG, "NULL argument");
+    if (!s->d.spb || !s->d.lcnt) return fail(DZG_E_ARG, "this solver keeps no live-entry lists");
+    HIP_OK(hipSetDevice(s->opts.device));
+    TRY(read_ctl(s));
+    return s->h_ctl->rl_listed;
 }
 
 extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
@@ -1632,7 +1796,9 @@ extern "C" int dzg_core_solve(const dzg_lp *lp, const dzg_opts *opts, dzg_result
         bool out_of_time = false;
         for (;;) {
             rc = dzg_solver_run(ss, 256);
-            if (rc != DZG_ITER_LIMIT || ss->h_ctl->iter >= strict.max_iter) break;
+            // (the solver's own limit: dzg_solver_create normalised max_iter <= 0 in ITS copy only,
+            // and a zero-filled dzg_opts from a C host must not read as "limit reached")
+            if (rc != DZG_ITER_LIMIT || ss->h_ctl->iter >= ss->opts.max_iter) break;
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (budget_s >= 0.0 && el > budget_s) { out_of_time = true; break; }
         }

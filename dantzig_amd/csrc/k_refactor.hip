@@ -219,17 +219,22 @@ __global__ __launch_bounds__(1024) void k_ref_lists(DzgCtl *ctl, int m,
 }
 
 // G[a][b] = A[drow[a], column of the b-th structural basic]; X = I.  grid (ceil(k/256), k)
+// own1 > own0: a PARTITIONED column-sharded rank holds the columns [own0, own1) only; the others
+// contribute +0.0 here and arrive through the sum over the ranks that follows (engine.hip: every
+// column has exactly one owner, so the sum is that owner's value, exactly)
 __global__ __launch_bounds__(256) void k_ref_gather(int k, const double *__restrict__ A,
                                                     long long lda, int col0,
                                                     const int *__restrict__ drow,
                                                     const int *__restrict__ scode,
                                                     double *__restrict__ G, double *__restrict__ X,
-                                                    long long ldg)
+                                                    long long ldg, int own0, int own1)
 {
     const int a = blockIdx.y;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= k) return;
-    G[(long long)a * ldg + b] = A[(long long)(scode[b] - col0) * lda + drow[a]];
+    const int code = scode[b];
+    const bool have = own1 <= own0 || (code >= own0 && code < own1);
+    G[(long long)a * ldg + b] = have ? A[(long long)(code - col0) * lda + drow[a]] : 0.0;
     X[(long long)a * ldg + b] = (a == b) ? 1.0 : 0.0;
 }
 
@@ -241,10 +246,12 @@ __global__ __launch_bounds__(256) void k_ref_scatter_csc(int k, const long long 
                                                          const double *__restrict__ cval, int col0,
                                                          const int *__restrict__ scode,
                                                          const int *__restrict__ rowmap,
-                                                         double *__restrict__ T, long long ldt)
+                                                         double *__restrict__ T, long long ldt,
+                                                         int own0, int own1)
 {
     const int b = blockIdx.x;
     if (b >= k) return;
+    if (own1 > own0 && (scode[b] < own0 || scode[b] >= own1)) return; // (another rank's column)
     const int code = scode[b] - col0;
     for (long long e = cptr[code] + threadIdx.x; e < cptr[code + 1]; e += blockDim.x) {
         const int a = rowmap[ridx[e]];
@@ -914,12 +921,15 @@ __global__ __launch_bounds__(256) void k_ref_gather_slack(int k, const double *_
                                                           long long lda, int col0,
                                                           const int *__restrict__ lrow,
                                                           const int *__restrict__ scode,
-                                                          double *__restrict__ As, long long ldas)
+                                                          double *__restrict__ As, long long ldas,
+                                                          int own0, int own1)
 {
     const int i = blockIdx.y;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= k) return;
-    As[(long long)i * ldas + b] = A[(long long)(scode[b] - col0) * lda + lrow[i]];
+    const int code = scode[b];
+    const bool have = own1 <= own0 || (code >= own0 && code < own1);
+    As[(long long)i * ldas + b] = have ? A[(long long)(code - col0) * lda + lrow[i]] : 0.0;
 }
 
 __global__ void k_ref_done(DzgCtl *ctl, const int *__restrict__ singular)
@@ -957,21 +967,48 @@ static void gemm_sub(int M, int N, int K, const double *A, long long lda, const 
                        K, A, lda, B, ldb, C, ldc, (const int *)nullptr);
 }
 
-void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, double *Tri,
-                         long long ldg,
-                         int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
-                         int *singular, hipStream_t st)
+// The refactorisation in three stages.  A rank of a PARTITIONED column-sharded solve holds its own
+// columns only: stage A gathers what it has of G = A[R, S] (zeros for the other ranks' columns),
+// stage B factorises and gathers what it has of the basic-slack rows A[L, S]; between the stages
+// the host sums the two blocks over the ranks (engine.hip: RCCL all-reduce, or a copy kernel in
+// the lockstep harness) -- a column has exactly one owner, so the sum is exact.  Everything else
+// is the same computation on every rank.  One GPU / replicated matrix: A, B, C back to back.
+static inline void own_range(const DzgDev &d, int &own0, int &own1)
+{
+    own0 = own1 = 0; // no mask
+    if (d.world > 1 && !d.repl) {
+        own0 = d.col0;
+        own1 = d.col1;
+        if (own1 <= own0) { own0 = -2; own1 = -1; } // (a rank without columns: no code matches)
+    }
+}
+
+void dzg_launch_refactor_a(const DzgDev &d, int k, double *G, double *X, long long ldg, int *scode,
+                           int *singular, hipStream_t st)
 {
     hipMemsetAsync(singular, 0, sizeof(int), st);
+    if (k <= 0) return;
+    int own0, own1;
+    own_range(d, own0, own1);
+    if (d.csc) {
+        hipLaunchKernelGGL(k_ref_identity, dim3((k + 255) / 256, k), dim3(256), 0, st, k, G, X, ldg);
+        hipLaunchKernelGGL(k_ref_scatter_csc, dim3(k), dim3(256), 0, st, k, d.cptr, d.ridx, d.cval,
+                           d.col0, scode, d.dslot, G, ldg, own0, own1);
+    } else {
+        hipLaunchKernelGGL(k_ref_gather, dim3((k + 255) / 256, k), dim3(256), 0, st, k, d.A, d.lda,
+                           d.col0, d.drow, scode, G, X, ldg, own0, own1);
+    }
+}
+
+// returns the block that stage C multiplies (nl x k, leading dimension ldg; to be summed over the
+// ranks of a partitioned solve first), nullptr when there is none
+double *dzg_launch_refactor_b(const DzgDev &d, int k, int nl, double *G, double *X, double *Pn, double *Tri,
+                              long long ldg,
+                              int *piv, int *spos, int *scode, int *lpos, int *lrow, int *lslot,
+                              int *singular, hipStream_t st)
+{
+    double *slack_block = nullptr;
     if (k > 0) {
-        if (d.csc) {
-            hipLaunchKernelGGL(k_ref_identity, dim3((k + 255) / 256, k), dim3(256), 0, st, k, G, X, ldg);
-            hipLaunchKernelGGL(k_ref_scatter_csc, dim3(k), dim3(256), 0, st, k, d.cptr, d.ridx, d.cval,
-                               d.col0, scode, d.dslot, G, ldg);
-        } else {
-            hipLaunchKernelGGL(k_ref_gather, dim3((k + 255) / 256, k), dim3(256), 0, st, k, d.A, d.lda,
-                               d.col0, d.drow, scode, G, X, ldg);
-        }
         // ---- LU of G with the forward substitution of X riding along.
         // Panels are 64 columns wide, but the rank-64 updates they would feed the trailing matrix
         // read and write every element of it (and of X) per 64 columns: two panels a, b are
@@ -1091,14 +1128,15 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, d
         if (d.spb) {
             // sparse-basis mode keeps the k x k block only (k_sparse.hip); rows in position order
             dzg_launch_sp_ref_copy(d, k, Xf, ldg, st);
-            hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);
-            return;
+            return nullptr;
         }
         // ---- Binv0 rows of the structural positions
         hipLaunchKernelGGL(k_ref_scatter, dim3((k + 255) / 256, k), dim3(256), 0, st, k, Xf, ldg, spos,
                            d.binv, d.ldb);
         // ---- Binv0 rows of the basic slacks: -A[r', S] * X   (A[r', S] goes into the free panel)
         if (nl > 0) {
+            int own0, own1;
+            own_range(d, own0, own1);
             if (d.csc) {
                 hipMemsetAsync(Wk, 0, sizeof(double) * (size_t)nl * (size_t)ldg, st);
                 hipLaunchKernelGGL(k_ref_lslot, dim3((d.m + 255) / 256), dim3(256), 0, st, d.m, nl, lrow,
@@ -1106,18 +1144,50 @@ void dzg_launch_refactor(const DzgDev &d, int k, int nl, double *G, double *X, d
                 hipLaunchKernelGGL(k_ref_lslot_fill, dim3((nl + 255) / 256), dim3(256), 0, st, nl, lrow,
                                    lslot);
                 hipLaunchKernelGGL(k_ref_scatter_csc, dim3(k), dim3(256), 0, st, k, d.cptr, d.ridx,
-                                   d.cval, d.col0, scode, lslot, Wk, ldg);
+                                   d.cval, d.col0, scode, lslot, Wk, ldg, own0, own1);
             } else {
                 hipLaunchKernelGGL(k_ref_gather_slack, dim3((k + 255) / 256, nl), dim3(256), 0, st, k,
-                                   d.A, d.lda, d.col0, lrow, scode, Wk, ldg);
+                                   d.A, d.lda, d.col0, lrow, scode, Wk, ldg, own0, own1);
             }
-            if (!std::getenv("DZG_REF_GEMM_STRIPS"))
-                hipLaunchKernelGGL((k_ref_gemm_lds<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
-                                   nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
-            else
-                hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
-                                   nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
+            slack_block = Wk;
         }
     }
+    return slack_block;
+}
+
+void dzg_launch_refactor_c(const DzgDev &d, int k, int nl, double *G, double *X, long long ldg,
+                           int *lpos, int *singular, hipStream_t st)
+{
+    if (k > 0 && nl > 0 && !d.spb) {
+        const double *Xf = G; // the finished inverse (stage B)
+        double *Wk = X;       // A[L, S]
+        if (!std::getenv("DZG_REF_GEMM_STRIPS"))
+            hipLaunchKernelGGL((k_ref_gemm_lds<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
+                               nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
+        else
+            hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
+                               nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
+    }
     hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);
+}
+
+// Lockstep harness (all ranks of a partitioned solve in one process on one GPU): every rank's
+// block := the sum of all ranks' blocks, element by element, ranks in order.  bufs[r] = rank r's
+// block (device array of device pointers), `count` doubles each.
+__global__ __launch_bounds__(256) void k_lockstep_sum(double *const *bufs, int world, long long count)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < count;
+         i += (long long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int r = 0; r < world; ++r) s += bufs[r][i];
+        for (int r = 0; r < world; ++r) bufs[r][i] = s;
+    }
+}
+
+void dzg_launch_lockstep_sum(double *const *bufs, int world, long long count, hipStream_t st)
+{
+    if (count <= 0) return;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_lockstep_sum, dim3((unsigned)blocks), dim3(256), 0, st, bufs, world, count);
 }

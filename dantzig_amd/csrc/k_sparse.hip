@@ -374,17 +374,40 @@ __global__ __launch_bounds__(256) void k_sp_btran(
     // live-entry lists of the columns (k_price_csc_rl): the leaving slack's row carries v = 1 in
     // the pricing pass that follows and joins R at this pivot: its entries join their columns'
     // lists here (a row has at most one entry per column: no two threads share a list)
-    if (lcnt && rl >= 0 && blockIdx.x == 0)
-        for (long long e = rptr[rl] + tid; e < rptr[rl + 1]; e += blockDim.x) {
-            const int col = cidx[e];
-            const long long at = cptr[col] + lcnt[col];
-            DzgLiveEntry en;
-            en.row = rl;
-            en.pad_ = 0;
-            en.val = rval[e];
-            lent[at] = en;
-            lcnt[col] += 1;
+    // The append is idempotent across a stop: a dual step's ratio test comes AFTER the pricing pass
+    // and may end the run before the pivot (DZG_NEAR_TIE, resumable); ctl->rl_listed remembers the
+    // row that is already listed, the resumed iteration -- the same decision from the same state --
+    // finds it and appends nothing, k_sp_pivot clears the mark when the row has joined R for good.
+    // (A pending row that is NOT this iteration's -- unreachable today -- is taken out first.)
+    if (lcnt && blockIdx.x == 0 && c.rl_listed != rl) { // (block-uniform: c is a snapshot)
+        const int pend = c.rl_listed;
+        if (pend >= 0) {
+            for (long long e = rptr[pend] + tid; e < rptr[pend + 1]; e += blockDim.x) {
+                const int col = cidx[e];
+                const long long base = cptr[col];
+                const int n = lcnt[col];
+                for (int i = 0; i < n; ++i)
+                    if (lent[base + i].row == pend) {
+                        lent[base + i] = lent[base + n - 1];
+                        lcnt[col] = n - 1;
+                        break;
+                    }
+            }
+            __syncthreads(); // a column may hold entries of both rows
         }
+        if (rl >= 0)
+            for (long long e = rptr[rl] + tid; e < rptr[rl + 1]; e += blockDim.x) {
+                const int col = cidx[e];
+                const long long at = cptr[col] + lcnt[col];
+                DzgLiveEntry en;
+                en.row = rl;
+                en.pad_ = 0;
+                en.val = rval[e];
+                lent[at] = en;
+                lcnt[col] += 1;
+            }
+        if (tid == 0) ctl->rl_listed = rl;
+    }
     // rows outside R: zero, except the leaving slack's own row
     for (int r = gid; r < m; r += stride)
         if (dslot[r] < 0) v[r] = (r == rl) ? 1.0 : 0.0;
@@ -556,6 +579,7 @@ __device__ __forceinline__ int sp_pivot_books(
     ctl->sp_mcol = mcol;
     ctl->sp_zcol = zcol;
     ctl->ncompact = k;
+    ctl->rl_listed = -1; // (the row k_sp_btran listed ahead of this pivot is a row of R now)
     // ---- swap, log, counters, list of nonbasic structural positions (as fast_pivot_books of k_fast.hip)
     const long long it = c.iter;
     if (it < log_cap) {
@@ -921,7 +945,7 @@ __global__ __launch_bounds__(256) void k_sp_init(DzgCtl *ctl, int m, int ns,
             }
         }
         if (acol_code) *acol_code = (int)0x80000000;
-        (void)ctl;
+        ctl->rl_listed = -1; // (k_sp_rlists, launched next, lists the rows of R and nothing else)
     }
 }
 

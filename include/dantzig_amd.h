@@ -460,6 +460,10 @@ int dzg_debug_hold_wait(void);
  * k_price_csc_rl) against their definition; returns the number of columns whose list is wrong
  * (0 = consistent), < 0 on error (no such lists: DZG_E_ARG); *entries = entries listed in all. */
 int64_t dzg_debug_live_lists(dzg_solver *s, int64_t *entries);
+/* Test hook: the constraint row whose entries k_sp_btran has listed ahead of a pivot that has not
+ * been executed yet (a run that stopped between BTRAN and the pivot, DZG_NEAR_TIE in a dual step's
+ * ratio test), -1 if none; < -1 on error.  dzg_debug_live_lists counts that row as listed. */
+int64_t dzg_debug_rl_listed(dzg_solver *s);
 
 /* Deterministic max-loc merge: largest ratio wins, lowest global position on ties --
  * the sequential first-wins rule of src/simplex.rs:432-435,456-459.  Returns the index

@@ -232,11 +232,34 @@ typedef struct {
     double *dx, *dz, *v;
 } ora_work;
 
+/* Input format for fixtures at sizes where a CSC with 64-bit indices does not fit the build
+ * container (32768 x 65536: 34 GB): row_idx == NULL means "val is the structural block, dense
+ * column-major m x (n - m); column j >= n - m is the unit column of row j - (n - m)" -- the
+ * benchmark convention of SURVEY 8(d).  The stored entries of a column are then its nonzeros in
+ * ascending row order, exactly what the reference's CSC holds (src/linalg.rs:254-270 drops exact
+ * zeros), so every loop below visits the same entries in the same order in both formats
+ * (tests/test_oracle_kats.py holds the two bit-equal). */
+static int dense_input(const ora_simplex *s) { return s->row_idx == NULL; }
+
 /* src/simplex.rs:270-272 basis_matrix + linalg.rs:236-238 to_dense */
 static void gather_basis(const ora_simplex *s, double *bm)
 {
     const int64_t m = s->m;
     for (int64_t i = 0; i < m * m; ++i) bm[i] = 0.0;
+    if (dense_input(s)) {
+        const int64_t ns = s->n - m;
+        for (int64_t c = 0; c < m; ++c) {
+            int64_t j = s->basis[c];
+            if (j >= ns) {
+                bm[(j - ns) * m + c] = 1.0;
+                continue;
+            }
+            const double *col = s->val + j * m;
+            for (int64_t r = 0; r < m; ++r)
+                if (col[r] != 0.0) bm[r * m + c] = col[r];
+        }
+        return;
+    }
     for (int64_t c = 0; c < m; ++c) {
         int64_t j = s->basis[c];
         for (int64_t e = s->col_ptr[j]; e < s->col_ptr[j + 1]; ++e)
@@ -244,11 +267,55 @@ static void gather_basis(const ora_simplex *s, double *bm)
     }
 }
 
+/* CscMatrix::column (src/linalg.rs:180-186) in either input format */
+static void column_of(const ora_simplex *s, int64_t j, double *out)
+{
+    if (!dense_input(s)) {
+        ora_csc_column(s->m, s->col_ptr, s->row_idx, s->val, j, out);
+        return;
+    }
+    const int64_t m = s->m, ns = s->n - m;
+    for (int64_t i = 0; i < m; ++i) out[i] = 0.0;
+    if (j >= ns) {
+        out[j - ns] = 1.0;
+        return;
+    }
+    const double *col = s->val + j * m;
+    for (int64_t r = 0; r < m; ++r)
+        if (col[r] != 0.0) out[r] = col[r];
+}
+
+/* collect_columns(n).neg_t_dot(v) (src/linalg.rs:188-207) in either input format */
+static void price(const ora_simplex *s, const double *v, double *out)
+{
+    const int64_t m = s->m, q = s->n - m;
+    if (!dense_input(s)) {
+        ora_csc_neg_t_dot(s->col_ptr, s->row_idx, s->val, s->nonbasis, q, v, out);
+        return;
+    }
+    for (int64_t k = 0; k < q; ++k) {
+        int64_t j = s->nonbasis[k];
+        double acc = 0.0;
+        if (j >= q) { /* ns == q: the unit column's one stored entry */
+            double prod = 1.0 * -v[j - q];
+            acc = acc + prod;
+        } else {
+            const double *col = s->val + j * m;
+            for (int64_t r = 0; r < m; ++r) {
+                if (col[r] == 0.0) continue; /* not a stored entry */
+                double prod = col[r] * -v[r];
+                acc = acc + prod;
+            }
+        }
+        out[k] = acc;
+    }
+}
+
 /* src/simplex.rs:226-229 solve_for_dx */
 static void solve_for_dx(const ora_simplex *s, ora_work *w, int64_t j)
 {
     gather_basis(s, w->bm); /* basis_matrix.clone().to_dense() */
-    ora_csc_column(s->m, s->col_ptr, s->row_idx, s->val, j, w->dx);
+    column_of(s, j, w->dx);
     ORA_LU(w->bm, s->m, w->p);
     ora_lu_solve(w->bm, s->m, w->p, w->dx);
 }
@@ -263,7 +330,7 @@ static void solve_for_dz(const ora_simplex *s, ora_work *w, int64_t pos)
     w->v[pos] = 1.0;
     ORA_LU(w->bt, m, w->p); /* a second, independent LU (App. A.4) */
     ora_lu_solve(w->bt, m, w->p, w->v);
-    ora_csc_neg_t_dot(s->col_ptr, s->row_idx, s->val, s->nonbasis, s->n - m, w->v, w->dz);
+    price(s, w->v, w->dz);
 }
 
 /* src/simplex.rs:253-268 Simplex::pivot + :239-251 swap */

@@ -89,7 +89,11 @@ int64_t ora_find_second_pivot(double mu, const double *y, const double *ybar,
 typedef struct {
     int64_t m, n;            /* rows, all columns incl. slacks              */
     const int64_t *col_ptr;  /* n+1                                          */
-    const int64_t *row_idx;  /* nnz, ascending within a column               */
+    const int64_t *row_idx;  /* nnz, ascending within a column; NULL: val is the
+                                structural block dense column-major m x (n-m), columns
+                                n-m..n-1 are the unit columns of rows 0..m-1 (fixtures at
+                                sizes whose 64-bit CSC does not fit the build container;
+                                same entries visited in the same order, exact zeros skipped) */
     const double *val;       /* nnz, no explicit zeros                       */
     const double *c;         /* n objective coefficients (core MAXIMISES)    */
     double constant;

@@ -9,7 +9,7 @@ every pivot: an interrupted run keeps what it has.  Each record is what
 src/simplex.rs:274-306,308-330 decides -- (kind, entering, leaving) -- with mu* of that
 iteration and the seconds of CPU the pivot took on one core of the machine that ran this.
 
-  python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots [--blocked] [--resume]
+  python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots [--blocked] [--resume] [--dense-input]
   (BASELINE config 3: 1003 8192 16384 8  -- about 6.5 minutes per pivot)
 
 --blocked: the twin library (oracle/dzg_oracle_blocked.c: Matrix::factorize applied block by
@@ -42,15 +42,29 @@ if __name__ == "__main__":
     path = os.path.join(ROOT, "tests", "golden",
                         f"oracle_{'blocked' if blocked else 'first'}_pivots_{seed}_{m}x{ns}.json")
     a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
-    sf = ora.stdform_from_dense(a, b, c)
-    del a
-    n, q = sf.n, sf.n - sf.m
-    basis, nonbasis = ora._i64(sf.basis).copy(), ora._i64(sf.nonbasis).copy()
-    x, z = ora._f64(sf.x).copy(), ora._f64(sf.z).copy()
-    xbar, zbar = np.ones(m), np.ones(q)
-    col_ptr, row_idx, val, cc = ora._i64(sf.col_ptr), ora._i64(sf.row_idx), ora._f64(sf.val), ora._f64(sf.c)
-    st = ora._Simplex(m, n, ora._p(col_ptr), ora._p(row_idx), ora._p(val), ora._p(cc), float(sf.constant),
-                      ora._p(basis), ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
+    if "--dense-input" in sys.argv:
+        # the oracle's dense-structural input format (dzg_oracle.h, row_idx == NULL): the generator's
+        # column-major block as it is, no 64-bit CSC beside it (34 GB at 32768 x 65536)
+        n, q = ns + m, ns
+        val = np.ascontiguousarray(a.T)  # (ns, m) C-contiguous == column-major m x ns: no copy
+        assert val.base is a.base or val.base is a or np.shares_memory(val, a)
+        basis, nonbasis = np.arange(ns, ns + m, dtype=np.int64), np.arange(ns, dtype=np.int64)
+        x, z = ora._f64(b).copy(), -ora._f64(c)
+        xbar, zbar = np.ones(m), np.ones(q)
+        cc = np.concatenate([ora._f64(c), np.zeros(m)])
+        col_ptr = np.zeros(1, dtype=np.int64)
+        st = ora._Simplex(m, n, ora._p(col_ptr), None, ora._p(val), ora._p(cc), 0.0,
+                          ora._p(basis), ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
+    else:
+        sf = ora.stdform_from_dense(a, b, c)
+        del a
+        n, q = sf.n, sf.n - sf.m
+        basis, nonbasis = ora._i64(sf.basis).copy(), ora._i64(sf.nonbasis).copy()
+        x, z = ora._f64(sf.x).copy(), ora._f64(sf.z).copy()
+        xbar, zbar = np.ones(m), np.ones(q)
+        col_ptr, row_idx, val, cc = ora._i64(sf.col_ptr), ora._i64(sf.row_idx), ora._f64(sf.val), ora._f64(sf.c)
+        st = ora._Simplex(m, n, ora._p(col_ptr), ora._p(row_idx), ora._p(val), ora._p(cc), float(sf.constant),
+                          ora._p(basis), ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
     ckpt = os.path.join(ROOT, "gpurun_out", f"oracle_ckpt_{'blocked' if blocked else 'first'}_{seed}_{m}x{ns}.npz")
     prior = None
     if "--resume" in sys.argv and os.path.exists(ckpt) and os.path.exists(path):

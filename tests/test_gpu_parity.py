@@ -1057,9 +1057,10 @@ def test_live_entry_pricing_keeps_its_lists_and_agrees_with_the_full_pass(core, 
                 chunks += 1
             live = s.result()
             bad, _ = _live_lists_bad(s)
-            # (a dual step that ends at its ratio test -- infeasible, or stopped at a near tie -- has
-            # already listed the leaving slack's row, which then never joined R: a final state)
-            assert bad == 0 or live.status in ("infeasible", "near_tie", "panic"), (seed, "end", bad, live.status)
+            # (a dual step that ends at its ratio test has listed the leaving slack's row already:
+            # ctl->rl_listed says so and the hook counts that row as listed -- consistent in every
+            # final state, resumable or not)
+            assert bad == 0, (seed, "end", bad, live.status)
         monkeypatch.setenv("DZG_SP_PRICE_FULL", "1")
         with core.Solver(lp, numerics=core.FAST, poll_interval=8, refactor_interval=interval) as s:
             chunks = 0
@@ -1074,6 +1075,89 @@ def test_live_entry_pricing_keeps_its_lists_and_agrees_with_the_full_pass(core, 
         if live.status == full.status == "optimal":
             assert abs(live.objective - full.objective) <= 1e-9 * max(1.0, abs(full.objective)), seed
     assert most > 0  # (some row did join R somewhere)
+
+
+def test_live_lists_survive_a_near_tie_stop_and_resume(core, monkeypatch):
+    """k_sp_btran lists the leaving slack's row BEFORE the dual ratio test, which
+    can stop the run with DZG_NEAR_TIE (resumable).  The resumed iteration must not list the row a
+    second time (dz would count it twice from then on).  Integer / 0-1 LPs on the sparse-basis path
+    in STOP mode, resumed at every stop: the lists equal their definition at every stop and at the
+    end, and the solve is, bit for bit, the one COUNT mode takes (a resume decides the pivot as FAST
+    sees it, which is all COUNT does)."""
+    import scipy.sparse as sp
+
+    from tests.lp_families import make_lp
+
+    monkeypatch.delenv("DZG_SP_PRICE_FULL", raising=False)
+    stops_seen = dual_stops = 0
+    for seed in list(range(8840, 8870)) + [8905]:
+        if seed == 8905:
+            rng = np.random.default_rng(seed)
+            a = (rng.uniform(size=(220, 500)) < 0.04) * rng.integers(-3, 4, (220, 500)).astype(np.float64)
+            b = rng.integers(-2, 9, 220).astype(np.float64)
+            c = rng.integers(-4, 5, 500).astype(np.float64)
+        else:
+            a, b, c = make_lp(seed, 1 + seed % 2, 2, 60)
+        acsc = sp.csc_matrix(a)
+        acsc.eliminate_zeros()
+        acsc.sort_indices()
+        lp = core.CoreLP.from_csc(a.shape[0], acsc.indptr, acsc.indices, acsc.data, b, c)
+        want = core.solve(lp, numerics=core.FAST, poll_interval=8, max_iter=4000)
+        with core.Solver(lp, numerics=core.FAST, poll_interval=8, max_iter=4000,
+                         near_tie_action=core.NEAR_TIE_STOP) as s:
+            status, stops = s.run(0), 0
+            while status == "near_tie":
+                bad, _ = _live_lists_bad(s)
+                assert bad == 0, (seed, "stop", stops, bad)
+                dual_stops += int(_ffi_ctl_rl_listed(s) >= 0)
+                stops += 1
+                assert stops < 5000
+                status = s.run(0)
+            got = s.result()
+            bad, _ = _live_lists_bad(s)
+            assert bad == 0, (seed, "end", bad, got.status)
+        stops_seen += stops
+        assert (got.status, got.iterations, got.pivots) == (want.status, want.iterations, want.pivots), seed
+        assert np.array_equal(got.x, want.x) and np.array_equal(got.z, want.z), seed
+        # (one pivot can stop twice -- at status() and again at its ratio test -- and a terminal verdict
+        # inside the tolerance is a stop too: at least as many stops as booked near ties)
+        assert got.near_ties == want.near_ties <= stops, (seed, got.near_ties, want.near_ties, stops)
+    assert stops_seen > 20 and dual_stops > 0  # (some stop fell between BTRAN and the pivot)
+
+
+def _ffi_ctl_rl_listed(s):
+    """ctl->rl_listed: the constraint row k_sp_btran has listed ahead of a pivot that has not been
+    executed (the run stopped between BTRAN and the pivot), -1 if none."""
+    import ctypes as C
+
+    from dantzig_amd import _ffi
+
+    fn = _ffi.lib().dzg_debug_rl_listed
+    fn.argtypes = [C.c_void_p]
+    fn.restype = C.c_int64
+    return int(fn(s._h))
+
+
+def test_auto_strict_resolve_with_a_zero_filled_max_iter(core):
+    """dzg_core_solve's STRICT re-solve loop compared the pivot count with the
+    CALLER's max_iter; a C host that zero-fills dzg_opts (0 = default) got DZG_ITER_LIMIT after the
+    first 256-pivot chunk.  An integer LP whose STRICT solve needs more than 256 pivots, max_iter = 0:
+    the outcome is the one max_iter = 10 000 000 gives."""
+    from tests.lp_families import log3, make_lp
+
+    found = None
+    for seed in range(9100, 9140):
+        a, b, c = make_lp(seed, 1, 200, 260)
+        lp = core.CoreLP.from_inequality_form(a, b, c)
+        r = core.core_solve(lp, numerics=core.AUTO, max_iter=10_000_000, log_cap=1 << 14)
+        if r.numerics == "strict" and r.iterations > 300 and r.status != "iter_limit":
+            found = (seed, lp, r)
+            break
+    assert found, "no integer LP with a STRICT re-solve of more than 300 pivots among the seeds"
+    seed, lp, want = found
+    got = core.core_solve(lp, numerics=core.AUTO, max_iter=0, log_cap=1 << 14)
+    assert (got.status, got.numerics, got.iterations) == (want.status, "strict", want.iterations), seed
+    assert log3(got.pivots) == log3(want.pivots)
 
 
 def test_row_wise_pricing_agrees_with_the_column_pass(core, monkeypatch):

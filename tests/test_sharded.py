@@ -442,3 +442,100 @@ def test_sharded_processes_on_one_gpu_exchange_over_gloo(world, seed, m, ns):
         assert [(k, e, l) for k, e, l, _ in pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
         assert [tuple(p) for p in pivots] == [tuple(p) for p in single.pivots]   # mu too, exactly
         assert x == single.x.tolist() and objective == single.objective
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sparse", [False, True])
+def test_partitioned_sharding_refactorises(sparse):
+    """a PARTITIONED column-sharded solver (a rank holds its own column block
+    only) refactorises too -- every rank gathers what it has of A[R, S] and A[L, S], the shares are
+    summed over the ranks (one owner per column: exact; RCCL all-reduce in dzg_shard_run, a copy
+    kernel in this lockstep harness), and every rank factorises the same matrix.  A rebuild every 40
+    pivots: the oracle's pivots, and the bits of the single-GPU solve that refactorises at the same
+    pivots (dense; the CSC single-GPU solver runs the sparse-basis path, another representation)."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import ShardedSolver, col_range, run_lockstep
+
+    world, seed, m, ns = 3, 41, 96, 250
+    if sparse:
+        cp, ri, val, b, c = core.gen_sparse_lp(seed, m, ns, 6)
+        import scipy.sparse as sp
+
+        a = sp.csc_matrix((val, ri, cp), shape=(m, ns)).toarray()
+        whole = core.CoreLP.from_csc(m, cp, ri, val, b, c)
+    else:
+        a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+        whole = core.CoreLP.from_inequality_form(a, b, c)
+    want = ora.simplex_solve(ora.stdform_from_dense(np.asarray(a), b, c))
+    single = None if sparse else core.solve(whole, numerics=core.FAST, poll_interval=8, refactor_interval=40)
+    solvers = []
+    try:
+        for r in range(world):
+            if sparse:
+                lp = whole
+            else:
+                begin, end = col_range(ns, r, world)
+                ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)
+                lp = core.CoreLP.from_inequality_block(ab, bb, cb, begin, end)
+            solvers.append(ShardedSolver(lp, r, world, poll_interval=8, refactor_interval=40,
+                                         stream=solvers[0].stream if solvers else 0))
+        assert all(s.record_doubles > 8 for s in solvers)   # partitioned: the column travels
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == want.status == "optimal"
+    for res in results:
+        assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+        assert res.refactors >= 2 and res.refactors == results[0].refactors
+        assert abs(res.objective - want.objective) <= 1e-9 * max(1.0, abs(want.objective))
+        if single is not None:
+            assert res.refactors == single.refactors
+            assert res.pivots == single.pivots and np.array_equal(res.x, single.x)
+            assert res.max_pivot_error == single.max_pivot_error
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("replicate", [False, True])
+def test_sharded_warm_start_from_a_non_slack_basis(replicate):
+    """A column-sharded solver created on a basis that is not the slack basis (the state a result
+    handed back: dzg_lp.xbar / zbar) factorises it at its first run, the ranks exchanging their
+    basic columns (partitioned) or after the last upload (replicated, a_is_block): the rest of the
+    solve is, bit for bit, the single-GPU solver's continuation from the same state."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import ShardedSolver, col_range, run_lockstep
+
+    world, seed, m, ns = 4, 42, 128, 300
+    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    whole = core.CoreLP.from_inequality_form(a, b, c)
+    with core.Solver(whole, numerics=core.FAST, poll_interval=8) as s:
+        assert s.run(150) == "iter_limit"
+        mid = s.result()
+    assert mid.dense_columns > 20
+    cont = core.solve(core.resumed_from(whole, mid), numerics=core.FAST, poll_interval=8)
+    assert cont.status == "optimal" and cont.refactors == 1
+    solvers = []
+    try:
+        for r in range(world):
+            begin, end = col_range(ns, r, world)
+            ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)
+            lp = core.resumed_from(core.CoreLP.from_inequality_block(ab, bb, cb, begin, end), mid)
+            solvers.append(ShardedSolver(lp, r, world, poll_interval=8, replicate=replicate,
+                                         stream=solvers[0].stream if solvers else 0))
+        if replicate:
+            for r, s in enumerate(solvers):
+                for other in range(world):
+                    if other != r:
+                        ob, oe = col_range(ns, other, world)
+                        s.upload_columns(ob, oe, np.asarray(a)[:, ob:oe])
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == "optimal"
+    for res in results:
+        assert res.refactors == 1
+        assert res.pivots == cont.pivots and np.array_equal(res.x, cont.x)
+        assert res.objective == cont.objective and np.array_equal(res.basis, cont.basis)
