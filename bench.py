@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F64_PEAK_TFLOPS = 46.9  # v_mfma_f64_16x16x4_f64, measured: profiles/r02_mfma_f64_peak_microbench.txt
+MFMA_F64_DATASHEET_TFLOPS = 78.6  # AMD's datasheet figure for fp64 matrix (SURVEY 8(d) names it)
 
 
 # The reference's algorithm (a dense LU of B and of B^T from scratch in every iteration) is far
@@ -194,7 +195,100 @@ def pmc_traffic(args) -> dict | None:
                     "included (all kernels of a pricing pass summed); FETCH_SIZE x2 (gfx950), KiB units"}
 
 
+def refactor_child(args) -> int:
+    """--refactor-child K: create a solver of the workload warm-started from a basis of K structural
+    columns -- dzg_solver_create factorises it on the device (csrc/k_refactor.hip) -- and exit.  Run
+    under `rocprofv3 --pmc` by pmc_mfma() below; prints the seconds of a second, timed
+    refactorisation (counters on: not a rate to quote)."""
+    from dantzig_amd import core
+
+    a, b, c = core.gen_dense_lp(seed=args.seed, m=args.rows, n_struct=args.cols)
+    lp = core.warm_started(core.CoreLP.from_inequality_form(a, b, c), args.refactor_child)
+    with core.Solver(lp, numerics=core.FAST, refactor_interval=-1) as s:
+        t0 = time.perf_counter()
+        s.refactor()
+        print(json.dumps({"k": args.refactor_child, "refactor_s": time.perf_counter() - t0}))
+    return 0
+
+
+def pmc_mfma(args, k: int) -> dict | None:
+    """MfmaUtil of the refactorisation: SQ_VALU_MFMA_BUSY_CYCLES over the SIMD cycles
+    the kernels were resident, from a rocprofv3 --pmc child (started BEFORE this process touches
+    the GPU) that factorises a basis of k structural columns twice (creation + one explicit call).
+    The counters are summed over the 8 XCDs per dispatch; a kernel's duration in cycles is
+    GRBM_GUI_ACTIVE / 8, the chip has 1024 SIMDs:  MfmaUtil = busy / (128 x GRBM_GUI_ACTIVE)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    out = tempfile.mkdtemp(prefix="dzg_mfma_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--output-format", "csv",
+               "-d", out, "--", sys.executable, os.path.abspath(__file__), "--refactor-child", str(k),
+               "--rows", str(args.rows), "--cols", str(args.cols), "--seed", str(args.seed)]
+        _run_in_own_group(cmd, "/tmp", dict(os.environ, TMPDIR="/tmp"), 300)
+        per = {}
+        for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    name = row["Kernel_Name"]
+                    if "k_ref_" not in name:
+                        continue
+                    short = name.split("(")[0].replace("void ", "").strip()
+                    e = per.setdefault(short, {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "n": 0})
+                    e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    e["n"] += row["Counter_Name"] == "GRBM_GUI_ACTIVE"
+        busy = sum(e["SQ_VALU_MFMA_BUSY_CYCLES"] for e in per.values())
+        active = sum(e["GRBM_GUI_ACTIVE"] for e in per.values())
+        if active <= 0:
+            return None
+        gemm = {n: e for n, e in per.items() if e["SQ_VALU_MFMA_BUSY_CYCLES"] > 0}
+        gb = sum(e["SQ_VALU_MFMA_BUSY_CYCLES"] for e in gemm.values())
+        ga = sum(e["GRBM_GUI_ACTIVE"] for e in gemm.values())
+        return {"k": k, "MfmaUtil": busy / (128.0 * active),
+                "MfmaUtil_inside_the_MFMA_kernels": gb / (128.0 * ga) if ga > 0 else None,
+                "share_of_kernel_time_in_MFMA_kernels": ga / active,
+                "kernels": {n: {"launches": e["n"], "MfmaUtil": e["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * e["GRBM_GUI_ACTIVE"])}
+                            for n, e in sorted(gemm.items()) if e["GRBM_GUI_ACTIVE"] > 0},
+                "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over every k_ref_* kernel of two "
+                        "refactorisations of a basis of k structural columns (child run, same workload): busy "
+                        "cycles / (128 x GRBM_GUI_ACTIVE) -- 1024 SIMDs, both counters summed over 8 XCDs"}
+    except Exception as exc:  # the profiler is optional
+        print(f"pmc mfma unavailable: {exc}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def refactor_at(rows, cols, seed, k: int) -> dict:
+    """One timed dzg_solver_refactor of a basis of k structural columns of the workload (the LP
+    warm-started there, unprofiled): seconds and TFLOP/s by the flop model of the `mfma` block."""
+    from dantzig_amd import core
+
+    a, b, c = core.gen_dense_lp(seed=seed, m=rows, n_struct=cols)
+    lp = core.warm_started(core.CoreLP.from_inequality_form(a, b, c), k)
+    with core.Solver(lp, numerics=core.FAST, refactor_interval=-1) as s:
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            s.refactor()
+            best = min(best, time.perf_counter() - t0)
+    flops = 2.0 * k ** 3 + 2.0 * (rows - k) * k ** 2
+    return {"k": k, "seconds": best, "achieved": flops / best / 1e12, "unit": "TFLOP/s",
+            "frac": flops / best / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            "frac_of_datasheet": flops / best / 1e12 / MFMA_F64_DATASHEET_TFLOPS,
+            "note": "best of three dzg_solver_refactor calls, wall clock around the call"}
+
+
 SECONDARY = {"rows": 32768, "cols": 65536, "seed": 1005, "steps": 300, "warmup": 50}
+# the same LP deep in its solve: warm-started from a basis of 16 384 structural columns (the compact
+# inverse 4.3 GB, a row-wise pricing pass 8.6 GB) -- the state the column- and row-sharded solve of
+# `bench.py --gpus N` is measured on as well ("deep" block there)
+SECONDARY_DEEP = {"warm_k": 16384, "steps": 300, "warmup": 50}
 
 
 def under_profiler() -> bool:
@@ -269,6 +363,7 @@ def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
            "ms_per_step": 1e3 * elapsed / max(done, 1),
            "k_at_start": ra.dense_columns, "k_at_end": rb.dense_columns,
            "max_pivot_error": rb.max_pivot_error, "near_ties": rb.near_ties,
+           "first_near_tie": rb.first_near_tie,
            "refactors": rb.refactors, "roofline": _pricing(ra, rb, kernel)}
     if status == "iter_limit":
         solver.set_profile((1 << _ffi.K_COUNT) - 1)
@@ -306,7 +401,7 @@ SEVEN_LAUNCHES = False  # --seven-launches: the FAST iteration as seven kernels 
 
 def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, warmup,
             late_pivots: int = 0, deep_pivots: int = 0, whole_solve: bool = False,
-            mfma_block: bool = False) -> dict:
+            mfma_block: bool = False, end_pivots: int = 0, warm_k: int = 0) -> dict:
     """One workload on one GPU: generate, upload (untimed), `warmup` pivots, then `steps` timed;
     with late_pivots > 0 a second timed region deep in the same solve (see _late_regime)."""
     from dantzig_amd import _ffi, core
@@ -318,6 +413,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
     else:
         a, b, c = core.gen_dense_lp(seed=seed, m=rows, n_struct=cols)
         lp = core.CoreLP.from_inequality_form(a, b, c)
+        if warm_k > 0:  # (the deep regime of the solve without the pivots that lead there)
+            lp = core.warm_started(lp, warm_k)
     t_gen = time.perf_counter() - t_gen
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
              "tree": core.PRICE_TREE}[price_name]
@@ -341,7 +438,7 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                          profile=1 << _ffi.K_PRICE, poll_interval=50,
                          seven_launches=1 if SEVEN_LAUNCHES else 0)
     t_up = time.perf_counter() - t_up
-    late = deep = whole = mfma = None
+    late = deep = whole = mfma = end = None
     try:
         status = solver.run(warmup) if warmup > 0 else "iter_limit"
         r0 = solver.result(log=False)
@@ -375,9 +472,14 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                         "peak_note": "v_mfma_f64_16x16x4_f64 measured on this chip by tools/mfma_f64_peak.hip "
                                      "(profiles/r02_mfma_f64_peak_microbench.txt); the datasheet's 78.6 is not "
                                      "reached by that instruction",
-                        "MfmaUtil": None,
-                        "MfmaUtil_note": "per-kernel MFMA busy cycles: profiles/r01_pmc_mfma_summary.txt, "
-                                         "profiles/r03_refactor_kernel_stats.csv (rocprofv3, separate runs)"}
+                        "frac_of_datasheet": flops / tr / 1e12 / MFMA_F64_DATASHEET_TFLOPS,
+                        "datasheet_peak": MFMA_F64_DATASHEET_TFLOPS,
+                        "MfmaUtil": None}  # (filled by main() from the rocprofv3 --pmc child)
+        if end_pivots > 0 and numerics_name == "fast" and sparse_per_col <= 0 and \
+                solver.result(log=False).status in ("iter_limit", "running"):
+            # the regime that owns the whole solve: k beyond rows_T, the pricing pass column-wise
+            # again and FTRAN streaming 8 m k bytes of the compact inverse
+            end = _late_regime(solver, solver.result(log=False), steps, end_pivots, kernel)
         if whole_solve and numerics_name == "fast":
             # the rest of the solve, to optimality (the untimed regime blocks above are part of the
             # same trajectory; pivots and seconds are those of this last stretch)
@@ -391,6 +493,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                      "value": (rb.iterations - ra.iterations) / tw if tw > 0 else float("nan"),
                      "unit": "iterations/s", "k_at_end": rb.dense_columns, "objective": rb.objective,
                      "max_pivot_error": rb.max_pivot_error, "near_ties": rb.near_ties,
+                     "first_near_tie": rb.first_near_tie, "state_drift": rb.state_drift,
+                     "price_pass_used": rb.price_pass_used,
                      "refactors": rb.refactors, "chain_fallbacks": rb.chain_fallbacks,
                      # the whole solve as one number: every pivot from the first over the time spent
                      # inside dzg_solver_run (the regime blocks above are stretches of this solve)
@@ -436,6 +540,9 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
             "max_pivot_error": r1.max_pivot_error,
             "near_ties": r1.near_ties,
             "first_near_tie": r1.first_near_tie,
+            "price_pass_used": {0: "none", 1: "rows", 2: "columns", 3: "rows then columns"}[r1.price_pass_used & 3],
+            "price_rows_copy": bool(r1.price_rows_copy),
+            "refactors": r1.refactors,
         },
         "roofline": _pricing(r0, r1, kernel),
     }
@@ -443,6 +550,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
         out["late"] = late
     if deep is not None:
         out["deep"] = deep
+    if end is not None:
+        out["end"] = end
     if mfma is not None:
         out["mfma"] = mfma
     if whole is not None:
@@ -470,6 +579,11 @@ def main() -> int:
     ap.add_argument("--deep-pivots", type=int, default=150000,
                     help="a third timed region after this many pivots (default 150000: k ~ 4000 on the "
                          "benchmark LP, ~30 s untimed); 0 or --no-late = skip")
+    ap.add_argument("--end-pivots", type=int, default=400000,
+                    help="a fourth timed region after this many pivots (default 400000: k ~ 7700 on the "
+                         "benchmark LP, the regime most of the solve's time is spent in); rides with the "
+                         "whole solve of the default workload, 0 = skip")
+    ap.add_argument("--refactor-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-mfma", action="store_true",
                     help="skip the timed refactorisation (the \"mfma\" block) after the timed regions")
     ap.add_argument("--whole-solve", action="store_true",
@@ -493,6 +607,8 @@ def main() -> int:
                          "one core) to anchor the extrapolation to the benchmark size; 0 = skip")
     args = ap.parse_args()
 
+    if args.refactor_child > 0:
+        return refactor_child(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -519,6 +635,10 @@ def main() -> int:
 
     # children first: no GPU state yet (and none at all under a profiler)
     traffic = None if (args.no_pmc_traffic or under_profiler()) else pmc_traffic(args)
+    default_dense = args.rows == 8192 and args.cols == 16384 and args.sparse_per_col == 0 \
+        and args.numerics == "fast"
+    mfma_wanted = default_dense and not (args.no_late or args.no_mfma or under_profiler())
+    mfma_pmc = pmc_mfma(args, args.rows) if (mfma_wanted and not args.no_pmc_traffic) else None
 
     from dantzig_amd import _ffi
 
@@ -530,11 +650,17 @@ def main() -> int:
     SEVEN_LAUNCHES = bool(args.seven_launches)
     deep_pivots = args.deep_pivots if (late_pivots > 0 and args.rows == 8192 and args.cols == 16384
                                        and args.sparse_per_col == 0) else 0
+    whole = (args.whole_solve or (deep_pivots > 0 and args.numerics == "fast")) and not args.no_whole_solve
     out = measure(args.rows, args.cols, args.seed, args.sparse_per_col, args.price, args.numerics,
-                  args.steps, args.warmup, late_pivots, deep_pivots,
-                  (args.whole_solve or (deep_pivots > 0 and args.numerics == "fast"))
-                  and not args.no_whole_solve,
-                  mfma_block=late_pivots > 0 and not args.no_mfma)
+                  args.steps, args.warmup, late_pivots, deep_pivots, whole,
+                  mfma_block=late_pivots > 0 and not args.no_mfma,
+                  end_pivots=args.end_pivots if (whole and deep_pivots > 0) else 0)
+    if "mfma" in out and mfma_wanted:
+        # config 3 is named after this: the refactorisation of the FULL basis (k = m = 8192), timed
+        # unprofiled, and its MFMA utilisation from the counters of the child run above
+        out["mfma"]["full_basis"] = refactor_at(args.rows, args.cols, args.seed, args.rows)
+        out["mfma"]["MfmaUtil"] = mfma_pmc["MfmaUtil"] if mfma_pmc else None
+        out["mfma"]["MfmaUtil_detail"] = mfma_pmc
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
     out["roofline"]["traffic_detail"] = traffic
     if ROWS_T is not None:
@@ -542,7 +668,7 @@ def main() -> int:
         # the same solve -- the fractions measured there, side by side (blocks "late" and "deep")
         regimes = {"k=%d..%d (timed region)" % (out["config"]["k_at_start"], out["config"]["k_at_end"]):
                    out["roofline"]["frac"]}
-        for name in ("late", "deep"):
+        for name in ("late", "deep", "end"):
             blk = out.get(name)
             if blk and "roofline" in blk:
                 regimes["k=%d..%d (%s)" % (blk["k_at_start"], blk["k_at_end"], name)] = blk["roofline"]["frac"]
@@ -560,8 +686,17 @@ def main() -> int:
                           SECONDARY["steps"], SECONDARY["warmup"])
             out["secondary"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step",
                                                     "config", "roofline")}
+            dp = SECONDARY_DEEP
+            sec = measure(SECONDARY["rows"], SECONDARY["cols"], SECONDARY["seed"], 0, "auto", "fast",
+                          dp["steps"], dp["warmup"], warm_k=dp["warm_k"])
+            out["secondary"]["deep"] = {k: sec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step",
+                                                            "config", "roofline")}
+            out["secondary"]["deep"]["note"] = (
+                "the same LP warm-started from a basis of %d structural columns (x = 1, z = -1; factorised "
+                "on the device before the warm-up): the one-GPU figure the `deep` block of `bench.py --gpus N` "
+                "stands beside" % dp["warm_k"])
         except Exception as exc:  # never lose the primary line to the secondary workload
-            out["secondary"] = {"error": f"{type(exc).__name__}: {exc}"}
+            out.setdefault("secondary", {})["error"] = f"{type(exc).__name__}: {exc}"
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, 2 * args.cpu_sample_rows, 1002,
                                            args.cpu_sample_pivots, args.rows, args.cpu_anchor_rows)

@@ -62,6 +62,7 @@ class Opts(C.Structure):
         ("a_is_block", C.c_int32), ("near_tie_action", C.c_int32),
         ("replicate_matrix", C.c_int32), ("auto_restart_rows", C.c_int32), ("tie_tol", C.c_double),
         ("seven_launches", C.c_int32), ("auto_strict_budget_s", C.c_int32),
+        ("shard_rows", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -80,7 +81,8 @@ class Result(C.Structure):
         ("price_bytes", C.c_double), ("solve_ms", C.c_double), ("max_pivot_error", C.c_double),
         ("near_ties", C.c_int64), ("first_near_tie", C.c_int64), ("min_margin", C.c_double),
         ("margins", C.c_void_p), ("dense_columns", C.c_int64), ("refactors", C.c_int64),
-        ("chain_fallbacks", C.c_int64),
+        ("chain_fallbacks", C.c_int64), ("price_pass_used", C.c_int32),
+        ("price_rows_copy", C.c_int32), ("state_drift", C.c_double),
     ]
 
 

@@ -94,6 +94,23 @@ class CoreLP:
                    row_idx=np.ascontiguousarray(row_idx, dtype=np.int32), val=f64(val))
 
 
+def warm_started(lp: CoreLP, k: int) -> CoreLP:
+    """The same LP started from the basis "first k structural columns in the place of the first k
+    slacks" (x = 1, z = -1: any state will do for a benchmark -- the engine factorises the basis and
+    pivots from there).  How the deep regimes of a solve -- a compact inverse k columns wide -- are
+    reached without running the hundreds of thousands of pivots that lead there (bench.py,
+    tests/test_gpu_fullsize.py); works on whole and on column-block LPs of the benchmark convention."""
+    import dataclasses
+
+    m, ns = lp.m, lp.n_struct
+    if lp.var_col is not None or not 0 <= k <= min(m, ns):
+        raise ValueError("warm_started: benchmark-convention LP and 0 <= k <= min(m, n_struct)")
+    basis = np.concatenate([np.arange(k), ns + np.arange(k, m)]).astype(np.int64)
+    nonbasis = np.concatenate([np.arange(k, ns), ns + np.arange(k)]).astype(np.int64)
+    return dataclasses.replace(lp, basis=basis, nonbasis=nonbasis, x=np.ones(m), z=-np.ones(ns),
+                               xbar=None, zbar=None)
+
+
 def resumed_from(lp: CoreLP, r) -> CoreLP:
     """The same LP in the state a CoreResult (or anything with basis, nonbasis, x, xbar, z, zbar)
     left it in: a solver created on it factorises that basis and carries the solve on."""
@@ -134,6 +151,18 @@ class CoreResult:
     dense_columns: int = 0              # k: structural basics = dense columns of the inverse
     refactors: int = 0
     chain_fallbacks: int = 0            # failed device-wide barriers recovered from (k_chain.hip)
+    price_pass_used: int = 0            # bit mask: 1 row-wise pricing pass ran, 2 column-wise
+    price_rows_copy: int = 0            # 1: the row-major copy of the matrix is resident
+    state_drift: float = 0.0            # carried x_B / z_N vs the fresh inverse at the last refactorisation
+
+
+def _counters(r) -> dict:
+    """The scalar tail of a dzg_result that every entry point reports alike."""
+    return dict(max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
+                first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin),
+                dense_columns=int(r.dense_columns), refactors=int(r.refactors),
+                chain_fallbacks=int(r.chain_fallbacks), price_pass_used=int(r.price_pass_used),
+                price_rows_copy=int(r.price_rows_copy), state_drift=float(r.state_drift))
 
 
 class Solver:
@@ -214,11 +243,8 @@ class Solver:
             xbar=xbar[:m].copy(), z=z[:q].copy(), zbar=zbar[:q].copy(), pivots=pivots,
             kernel_ms={k: r.kernel_ms[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
             kernel_launches={k: r.kernel_launches[i] for i, k in enumerate(_ffi.KERNEL_CLASSES)},
-            price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms),
-            max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
-            first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin), margins=margins,
-            dense_columns=int(r.dense_columns), refactors=int(r.refactors),
-            chain_fallbacks=int(r.chain_fallbacks))
+            price_bytes=float(r.price_bytes), solve_ms=float(r.solve_ms), margins=margins,
+            **_counters(r))
 
     def set_profile(self, mask: int) -> None:
         """Which kernel classes (bits 1 << _ffi.K_*) the following runs time with HIP events."""
@@ -279,10 +305,7 @@ def core_solve(lp: CoreLP, log_cap: int = 1 << 20, **opts) -> CoreResult:
             iterations=int(r.iterations), objective=float(r.objective),
             basis=basis[:m].copy(), nonbasis=nonbasis[:q].copy(), x=x[:m].copy(),
             xbar=xbar[:m].copy(), z=z[:q].copy(), zbar=zbar[:q].copy(), pivots=pivots,
-            max_pivot_error=float(r.max_pivot_error), near_ties=int(r.near_ties),
-            first_near_tie=int(r.first_near_tie), min_margin=float(r.min_margin),
-            margins=margins[:cnt].copy(), dense_columns=int(r.dense_columns),
-            refactors=int(r.refactors), chain_fallbacks=int(r.chain_fallbacks))
+            margins=margins[:cnt].copy(), **_counters(r))
 
 
 def core_solve_full_csc(m: int, n: int, col_ptr, row_idx, val, c, constant, basis, nonbasis, x, z,
@@ -318,11 +341,7 @@ def core_solve_full_csc(m: int, n: int, col_ptr, row_idx, val, c, constant, basi
         numerics="strict" if r.numerics_used == STRICT else "fast",
         iterations=int(r.iterations), objective=float(r.objective),
         basis=basis[:m], nonbasis=nonbasis[:q], x=x[:m], xbar=xbar[:m].copy(), z=z[:q],
-        zbar=zbar[:q].copy(), pivots=pivots, max_pivot_error=float(r.max_pivot_error),
-        near_ties=int(r.near_ties), first_near_tie=int(r.first_near_tie),
-        min_margin=float(r.min_margin), margins=margins[:cnt].copy(),
-        dense_columns=int(r.dense_columns), refactors=int(r.refactors),
-        chain_fallbacks=int(r.chain_fallbacks))
+        zbar=zbar[:q].copy(), pivots=pivots, margins=margins[:cnt].copy(), **_counters(r))
 
 
 # ------------------------------------------------------------------ synthetic LPs

@@ -78,6 +78,12 @@ struct DzgCtl {
     int neta_cur, k_cur;  // neta and ncompact of the iteration in flight
     int bar_timeout;      // a device-wide barrier gave up waiting (status is DZG_PANIC then)
     double xp, xbp;       // x, xbar at the leaving position
+    // row-sharded basis side (k_rowshard.hip): the leaving row's owner and dx at the leaving position
+    // as the records / the replicated row arithmetic delivered them
+    int leave_src;        // rank whose record carries row p of the inverse (exchange 1: dual step,
+                          // exchange 2: primal step)
+    int price_mask;       // pricing passes the executed pivots ran: 1 row-wise, 2 column-wise
+    double dxp;
     unsigned long long bar_gen; // device-wide barriers passed so far (k_chain.hip)
 };
 
@@ -86,6 +92,11 @@ struct DzgCtl {
 #define DZG_NB_GEMV 512   // blocks of k_fast_gemv        -> primal ratio partials
 #define DZG_NW_PRICE 1024 // waves of the pricing kernels -> dual ratio partials
 #define DZG_RMAX 64       // eta-file capacity = rank of one MFMA flush
+#define DZG_PR_GMAX 32    // row groups of the row-wise pricing pass at most (k_price_rows)
+#define DZG_PR_BATCH 16   // rows per group at least: G = min(DZG_PR_GMAX, ceil((k + 1) / 16))
+// exchange record of a row-sharded rank (include/dantzig_amd.h): header, U_t[p], column, row
+#define DZG_RS_HDR 16
+#define DZG_RS_COL (DZG_RS_HDR + DZG_RMAX)
 
 // argmax candidate: k < 0 means "none"
 struct DzgCand {
@@ -387,6 +398,10 @@ struct DzgDev {
                          // of them empty -- 600 us per flush, 9 us per pivot
     int price_cols_hint; // host's last reading of ctl->nb_struct (0: unknown): picks the pricing
                          // kernel's pass shape; any shape is correct for any count
+    // opts.shard_rows (k_rowshard.hip): this rank owns the rows [rs_r0, rs_r1) of x, xbar, dx, Binv0
+    // and U; rs == 0: all of them (rs_r0 = 0, rs_r1 = m)
+    int rs, rs_r0, rs_r1;
+    long long rs_mcol;   // doubles of a record's column section (0: the matrix is replicated)
 };
 
 #ifdef __HIPCC__
@@ -416,7 +431,7 @@ int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *
 
 // k_price.hip
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
-void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st);
+void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind = -1);
 void dzg_launch_transpose_to_rows(const double *A, long long lda, int m, int n, double *At,
                                   long long ldt, hipStream_t st);
 int dzg_price_rows_groups(void);
@@ -471,6 +486,16 @@ void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
                            unsigned long long *dbg, int only_partials, int nrz, const double *xrecv,
                            hipStream_t st);
+
+// k_rowshard.hip: column sharding with the basis side sharded by rows too (opts.shard_rows)
+void dzg_launch_rs_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
+void dzg_launch_rs_select(const DzgDev &d, int mode, const double *xrecv, hipStream_t st);
+void dzg_launch_rs_gemv(const DzgDev &d, int kind, const double *xrecv1, const double *xrecv2,
+                        hipStream_t st);
+void dzg_launch_rs_books(const DzgDev &d, const double *xrecv1, hipStream_t st);
+void dzg_launch_rs_lockstep_gather(double *const *ptrs, int world, int m, int slice, hipStream_t st);
+void dzg_launch_rs_pack(const DzgDev &d, int slice, double *send, hipStream_t st);
+void dzg_launch_rs_unpack(const DzgDev &d, int slice, const double *recv, hipStream_t st);
 
 // k_sparse.hip
 void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st);

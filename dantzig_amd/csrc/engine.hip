@@ -117,6 +117,7 @@ struct dzg_solver {
                                  // triggers a refactorisation
     double max_err_life = 0.0; // largest ctl->max_pivot_err ever read (the device value restarts
                                // at every refactorisation)
+    double state_drift = 0.0;  // carried x_B / z_N against the fresh inverse, at the last refactorisation
     // FAST, dense, one GPU: the three-launch chain (k_chain.hip)
     unsigned long long *chain_bar = nullptr; // barrier counters (cleared only by chain_recover)
     unsigned long long *chain_dbg = nullptr; // DZG_CHAIN_DEBUG=1: phase clocks of workgroup 0
@@ -129,6 +130,13 @@ struct dzg_solver {
     // column sharding
     void *comm = nullptr;                  // ncclComm_t
     double *xsend = nullptr, *xrecv1 = nullptr, *xrecv2 = nullptr;
+    // opts.shard_rows (k_rowshard.hip)
+    long long xstride_max = 0;             // largest record (room for a row of m entries); d.xstride is
+                                           // what the batch in flight sends
+    const double *rs_recv1 = nullptr;      // records of exchange 1 (phase 3 of a dual step reads the
+                                           // leaving row from them)
+    int rs_slice = 0;                      // rows per rank
+    double *rs_gsend = nullptr, *rs_grecv = nullptr; // x / xbar slices on their way to every rank
     // profiling
     std::vector<hipEvent_t> ev; // [batch slot][class][2]
     double kernel_ms[DZG_K_COUNT] = {};
@@ -383,6 +391,26 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                                                            : lp->a + (size_t)d.col0 * (size_t)lp->lda;
 
     d.csc = (ns > 0 && !lp->a) ? 1 : 0;
+    // opts.shard_rows: the basis side sharded by rows as well (k_rowshard.hip)
+    d.rs = 0;
+    d.rs_r0 = 0;
+    d.rs_r1 = m;
+    d.rs_mcol = 0;
+    if (o.shard_rows && d.world > 1) {
+        if (d.csc) return fail(DZG_E_ARG, "opts.shard_rows needs a dense matrix");
+        if (o.price_kernel != DZG_PRICE_AUTO && o.price_kernel != DZG_PRICE_TREE)
+            return fail(DZG_E_ARG, "opts.shard_rows prices with the AUTO / TREE kernels (every rank "
+                                   "re-derives dz of the entering column in their summation order)");
+        d.rs = 1;
+        s->rs_slice = (int)((((long long)m + d.world - 1) / d.world + 15) / 16 * 16);
+        if (s->rs_slice < 16) s->rs_slice = 16;
+        const long long r0 = (long long)d.rank * s->rs_slice;
+        d.rs_r0 = (int)(r0 < m ? r0 : m);
+        d.rs_r1 = (int)(r0 + s->rs_slice < m ? r0 + s->rs_slice : m);
+        d.rs_mcol = d.repl ? 0 : ((long long)m + 15) / 16 * 16;
+        s->xstride_max = DZG_RS_COL + d.rs_mcol + ((long long)m + 2 + 15) / 16 * 16;
+        d.xstride = s->xstride_max;
+    }
     if (d.csc) {
         // sparse mode: the owned columns stay CSC on the device (12 bytes per nonzero); explicit
         // zeros are dropped like the reference's From<&Matrix> for CscMatrix (src/linalg.rs:261)
@@ -610,7 +638,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             HIP_OK(hipMemsetAsync(d.dxs, 0, sizeof(double) * (size_t)(m ? m : 1), s->st));
         }
         // dense matrix: one GPU, or a column-sharded rank (replicated or partitioned storage)
-        if (!d.csc && !o.seven_launches) { // (a partitioned rank takes the column from the record)
+        if (!d.csc && !o.seven_launches && !d.rs) { // (a partitioned rank takes the column from the record)
             // the chain's barriers need every workgroup resident at once: one per CU, and the
             // runtime must agree that a workgroup of either kernel fits a CU at all (registers,
             // 136 KB of LDS); otherwise the barrier-free seven launches run
@@ -1327,7 +1355,10 @@ extern "C" int dzg_shard_phase1(dzg_solver *s, double *send_dev)
 {
     if (!s || !send_dev || s->numerics != DZG_NUMERICS_FAST) return fail(DZG_E_ARG, "phase1");
     phase_stamp(s, DZG_K_STATUS, 0);
-    dzg_launch_shard_propose(s->d, 0, 0, send_dev, s->st);
+    if (s->d.rs)
+        dzg_launch_rs_propose(s->d, 0, 0, send_dev, s->st);
+    else
+        dzg_launch_shard_propose(s->d, 0, 0, send_dev, s->st);
     phase_stamp(s, DZG_K_STATUS, 1);
     return 0;
 }
@@ -1339,6 +1370,20 @@ extern "C" int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *s
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     const int pk = price_kernel_for(s);
+    if (d.rs) { // the basis side is row-sharded: k_rowshard.hip
+        s->rs_recv1 = recv_dev;
+        phase_stamp(s, DZG_K_FTRAN, 0);
+        dzg_launch_rs_select(d, 0, recv_dev, st);                       // merge + status() (+ prep / v)
+        dzg_launch_rs_gemv(d, DZG_STEP_PRIMAL, recv_dev, nullptr, st); // primal: FTRAN, own rows
+        phase_stamp(s, DZG_K_FTRAN, 1);
+        phase_stamp(s, DZG_K_PRICE, 0);
+        dzg_launch_price_fast(d, pk, st, DZG_STEP_DUAL);                // dual: pricing, own columns
+        phase_stamp(s, DZG_K_PRICE, 1);
+        phase_stamp(s, DZG_K_RATIO, 0);
+        dzg_launch_rs_propose(d, 1, price_partials_for(s, pk), send_dev, st);
+        phase_stamp(s, DZG_K_RATIO, 1);
+        return 0;
+    }
     phase_stamp(s, DZG_K_FTRAN, 0);
     if (s->batch_chain) { // the three kernels below in one launch, k_chain.hip
         dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, recv_dev, st);
@@ -1363,7 +1408,14 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     phase_stamp(s, DZG_K_UPDATE, 0);
-    if (s->batch_chain) {
+    if (d.rs) {
+        if (!s->rs_recv1) return fail(DZG_E_ARG, "phase3 before phase2");
+        dzg_launch_rs_select(d, 1, recv_dev, st);                          // merge (+ prep / v)
+        dzg_launch_price_fast(d, price_kernel_for(s), st, DZG_STEP_PRIMAL); // primal: pricing
+        dzg_launch_rs_gemv(d, DZG_STEP_DUAL, s->rs_recv1, recv_dev, st);   // dual: FTRAN + dx_p
+        dzg_launch_rs_books(d, s->rs_recv1, st);
+        dzg_launch_fast_update(d, 0, st);
+    } else if (s->batch_chain) {
         dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0, 0, recv_dev, st);
     } else {
         dzg_launch_fast_select_prep(d, 5, 0, recv_dev, st);    // merge + (dual) FTRAN prep
@@ -1375,6 +1427,34 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
         s->since_flush = 0;
     }
     phase_stamp(s, DZG_K_UPDATE, 1);
+    return 0;
+}
+
+// Row-sharded ranks (opts.shard_rows): a record carries a row of the compact inverse, k entries
+// wide; the batch being enqueued sends what its bound on k needs (k grows by at most one per
+// pivot), not the room for m entries the buffers hold.  0: back to the largest record.
+static void rs_batch_stride(dzg_solver *s, int k_bound)
+{
+    if (!s->d.rs) return;
+    long long krow = ((long long)s->d.m + 2 + 15) / 16 * 16;
+    if (k_bound > 0) {
+        const long long need = ((long long)k_bound + 2 + 15) / 16 * 16;
+        if (need < krow) krow = need;
+    }
+    s->d.xstride = DZG_RS_COL + s->d.rs_mcol + krow;
+}
+
+// x and xbar live on their rows' owners while a row-sharded solve runs: every rank gets all of them
+// when a run returns (RCCL: one all-gather of the two slices)
+static int rs_gather_state(dzg_solver *s)
+{
+    if (!s->d.rs) return 0;
+    Rccl &r = rccl();
+    dzg_launch_rs_pack(s->d, s->rs_slice, s->rs_gsend, s->st);
+    if (r.AllGather(s->rs_gsend, s->rs_grecv, (size_t)2 * s->rs_slice, kNcclFloat64, s->comm, s->st) != 0)
+        return fail(DZG_E_DEVICE, "ncclAllGather (x, xbar of a row-sharded solve)");
+    dzg_launch_rs_unpack(s->d, s->rs_slice, s->rs_grecv, s->st);
+    HIP_OK(hipStreamSynchronize(s->st));
     return 0;
 }
 
@@ -1401,7 +1481,11 @@ extern "C" int dzg_comm_unique_id(void *unique_id_128)
 static int shard_buffers(dzg_solver *s)
 {
     if (s->xsend) return 0;
-    const size_t n = (size_t)s->d.xstride;
+    const size_t n = (size_t)(s->xstride_max ? s->xstride_max : s->d.xstride);
+    if (s->d.rs) {
+        TRY(dev_alloc(s, &s->rs_gsend, (size_t)2 * s->rs_slice));
+        TRY(dev_alloc(s, &s->rs_grecv, (size_t)2 * s->rs_slice * (size_t)s->d.world));
+    }
     TRY(dev_alloc(s, &s->xsend, n));
     TRY(dev_alloc(s, &s->xrecv1, n * (size_t)s->d.world));
     TRY(dev_alloc(s, &s->xrecv2, n * (size_t)s->d.world));
@@ -1442,7 +1526,7 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         if (rc0 != DZG_RUNNING) return rc0;
     }
     Rccl &r = rccl();
-    const size_t n = (size_t)s->d.xstride;
+    size_t n = (size_t)s->d.xstride;
     auto t0 = std::chrono::steady_clock::now();
     if (s->pending_refactor) TRY(refactor_now(s)); // a warm start: the starting basis, all ranks together
     for (;;) {
@@ -1459,6 +1543,8 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         s->d.price_cols_hint = (int)s->h_ctl->nb_struct + batch;
         s->d.k_hint = (int)s->h_ctl->ncompact + batch; // bounds on k for the launches of this batch
         s->d.k_lo_hint = (int)s->h_ctl->ncompact > batch ? (int)s->h_ctl->ncompact - batch : 0;
+        rs_batch_stride(s, s->d.k_hint);
+        n = (size_t)s->d.xstride;
         for (int b = 0; b < batch; ++b) {
             s->prof_slot = s->opts.profile ? b : -1;
             TRY(dzg_shard_phase1(s, s->xsend));
@@ -1475,6 +1561,7 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         }
         s->prof_slot = -1;
         s->d.k_hint = s->d.k_lo_hint = 0;
+        rs_batch_stride(s, 0);
         TRY(read_ctl(s));
         HIP_OK(hipGetLastError());
         if (s->h_ctl->bar_timeout)
@@ -1487,6 +1574,7 @@ extern "C" int dzg_shard_run(dzg_solver *s, int64_t max_new_iters)
         TRY(health_check(s, &stop));
         if (stop) break;
     }
+    TRY(rs_gather_state(s));
     s->solve_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return s->h_ctl->status;
 }
@@ -1495,7 +1583,8 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
 {
     if (!sv || world < 1) return fail(DZG_E_ARG, "lockstep");
     for (int r = 0; r < world; ++r) {
-        if (!sv[r] || sv[r]->d.world != world || sv[r]->d.rank != r || sv[r]->st != sv[0]->st)
+        if (!sv[r] || sv[r]->d.world != world || sv[r]->d.rank != r || sv[r]->st != sv[0]->st ||
+            sv[r]->d.rs != sv[0]->d.rs)
             return fail(DZG_E_ARG, "lockstep: solvers must be ranks 0..world-1 on one stream");
         TRY(shard_buffers(sv[r]));
     }
@@ -1542,6 +1631,7 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
             sv[r]->d.price_cols_hint = (int)sv[r]->h_ctl->nb_struct + batch;
             sv[r]->d.k_hint = (int)sv[r]->h_ctl->ncompact + batch;
             sv[r]->d.k_lo_hint = (int)sv[r]->h_ctl->ncompact > batch ? (int)sv[r]->h_ctl->ncompact - batch : 0;
+            rs_batch_stride(sv[r], sv[r]->d.k_hint);
         }
         for (int b = 0; b < batch; ++b) {
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase1(sv[r], sv[r]->xsend));
@@ -1550,7 +1640,10 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
             TRY(exchange(true));
             for (int r = 0; r < world; ++r) TRY(dzg_shard_phase3(sv[r], sv[r]->xrecv2));
         }
-        for (int r = 0; r < world; ++r) sv[r]->d.k_hint = sv[r]->d.k_lo_hint = 0;
+        for (int r = 0; r < world; ++r) {
+            sv[r]->d.k_hint = sv[r]->d.k_lo_hint = 0;
+            rs_batch_stride(sv[r], 0);
+        }
         for (int r = 0; r < world; ++r) TRY(read_ctl(sv[r]));
         HIP_OK(hipGetLastError());
         for (int r = 0; r < world; ++r)
@@ -1580,6 +1673,19 @@ extern "C" int dzg_shard_run_lockstep(dzg_solver **sv, int32_t world, int64_t ma
                 stop = stop || one;
             }
         if (stop) break;
+    }
+    if (sv[0]->d.rs) { // x, xbar of every rank's rows into every rank's arrays
+        std::vector<double *> xp((size_t)2 * world);
+        for (int r = 0; r < world; ++r) {
+            xp[(size_t)r] = sv[r]->d.x;
+            xp[(size_t)world + r] = sv[r]->d.xbar;
+        }
+        double **dxp = nullptr;
+        HIP_OK(hipMalloc(&dxp, sizeof(double *) * xp.size()));
+        struct FreeX { double **p; ~FreeX() { hipFree(p); } } free_xp{dxp};
+        HIP_OK(hipMemcpy(dxp, xp.data(), sizeof(double *) * xp.size(), hipMemcpyHostToDevice));
+        dzg_launch_rs_lockstep_gather(dxp, world, sv[0]->d.m, sv[0]->rs_slice, st);
+        HIP_OK(hipStreamSynchronize(st));
     }
     return sv[0]->h_ctl->status;
 }
@@ -1733,6 +1839,9 @@ extern "C" int dzg_solver_result(dzg_solver *s, dzg_result *res)
     res->dense_columns = s->numerics == DZG_NUMERICS_FAST ? s->h_ctl->ncompact : 0;
     res->refactors = s->refactors;
     res->chain_fallbacks = s->chain_fallbacks;
+    res->price_pass_used = s->numerics == DZG_NUMERICS_FAST && !s->d.csc ? s->h_ctl->price_mask : 0;
+    res->price_rows_copy = s->d.At ? 1 : 0;
+    res->state_drift = s->state_drift;
     if (res->margins && res->log_cap > 0 && s->numerics == DZG_NUMERICS_FAST) {
         long long cnt = res->iterations < d.log_cap ? res->iterations : d.log_cap;
         if (cnt > res->log_cap) cnt = res->log_cap;

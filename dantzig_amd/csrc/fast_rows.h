@@ -190,6 +190,7 @@ struct DzgPivotArgs {
     long long log_cap;
     int rows_T;        // row-wise pricing while ncompact < rows_T (0: never), rows of rows_ld doubles
     long long rows_ld;
+    int row0, row1;    // rows of Binv0 this device holds ([0, m) unless the basis side is row-sharded)
 };
 
 inline DzgPivotArgs dzg_pivot_args(const DzgDev &d)
@@ -205,6 +206,7 @@ inline DzgPivotArgs dzg_pivot_args(const DzgDev &d)
     pa.log_kind = d.log_kind; pa.log_enter = d.log_enter; pa.log_leave = d.log_leave;
     pa.log_mu = d.log_mu; pa.log_margin = d.log_margin; pa.log_cap = d.log_cap;
     pa.rows_T = d.At ? d.rows_T : 0; pa.rows_ld = d.ldt;
+    pa.row0 = d.rs ? d.rs_r0 : 0; pa.row1 = d.rs ? d.rs_r1 : d.m;
     return pa;
 }
 
@@ -312,7 +314,8 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
         const int k = s_k, rl = -1 - ci;
         drow[k] = rl;
         dslot[rl] = k;
-        if (!chain) binv[(long long)p * ldb + k] = 1.0; // columns >= ncompact are kept zero
+        if (!chain && p >= pa.row0 && p < pa.row1)
+            binv[(long long)p * ldb + k] = 1.0; // columns >= ncompact are kept zero
         s_k = k + 1;
     }
     // ---- an entering slack makes the column of its row the unit vector e_p again: its compact
@@ -348,6 +351,7 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
     // algorithmic bytes of this iteration's pricing pass; sparse: 12 B per stored
     // entry of the nonbasic structural columns + their column pointers
     double bytes = c.price_bytes;
+    if (!cptr) ctl->price_mask = c.price_mask | ((pa.rows_T > 0 && c.ncompact < pa.rows_T) ? 1 : 2);
     if (cptr)
         bytes += 12.0 * (double)c.nb_nnz + 4.0 * (double)(s + 1) + 8.0 * (double)m + 32.0 * (double)q;
     else if (pa.rows_T > 0 && c.ncompact < pa.rows_T) {

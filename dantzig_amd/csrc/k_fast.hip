@@ -318,14 +318,18 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
                                                      const double *__restrict__ v,
                                                      double *__restrict__ U, long long ldu,
                                                      double *__restrict__ W, long long ldw,
-                                                     double *__restrict__ binv, long long ldb)
+                                                     double *__restrict__ binv, long long ldb,
+                                                     int r0, int r1, int rowshard)
 {
+    // [r0, r1): the rows of x, xbar, U and Binv0 this device keeps -- [0, m) unless the basis side is
+    // row-sharded (k_rowshard.hip), where dx_p comes from its owner's record (ctl->dxp) and the eta
+    // row W_t = v, which every rank holds whole, is written for all m rows
     const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
     const int p = c.leave_pos, r = c.enter_pos;
     if (!only_partials && c.del_last >= 0) { // compact column delete booked by fast_pivot_books
         const int ce = c.del_ce, last = c.del_last;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        for (int i = r0 + blockIdx.x * blockDim.x + threadIdx.x; i < r1; i += gridDim.x * blockDim.x) {
             double *row = binv + (long long)i * ldb;
             if (ce != last) row[ce] = row[last];
             row[last] = 0.0;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->fp_count = (int)gridDim.x;
     const int teta = neta_new - 1;
     const int wzero = c.enter_code < 0 ? -1 - c.enter_code : -1;
-    const double rdxp = only_partials ? 0.0 : 1.0 / dx[p];
+    const double rdxp = only_partials ? 0.0 : 1.0 / (rowshard ? c.dxp : dx[p]);
     double *ut = U + (long long)(teta < 0 ? 0 : teta) * ldu;
     double *wt = W + (long long)(teta < 0 ? 0 : teta) * ldw;
     const double t = c.t, s = c.s, tbar = c.tbar, sbar = c.sbar;
@@ -353,7 +357,10 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
     // not have -- with any ratio -- unless its numerator makes the ratio hopelessly negative
     const double tau = c.tau, inf = __builtin_inf();
     DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    if (!only_partials && rowshard) // (the rows of W_t outside this rank's share of x)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+            if (i < r0 || i >= r1) wt[i] = (i == wzero) ? 0.0 : v[i];
+    for (int i = r0 + blockIdx.x * blockDim.x + threadIdx.x; i < r1; i += stride) {
         double xi = x[i], xb = xbar[i];
         if (!only_partials) {
             const double d = dx[i];
@@ -699,7 +706,7 @@ void dzg_launch_fast_update(const DzgDev &d, int only_partials, hipStream_t st)
     hipLaunchKernelGGL(k_fast_update, dim3(DZG_NB_UPD), dim3(256), 0, st, d.ctl, only_partials, d.x,
                        d.xbar, d.z, d.zbar, d.dx, d.dz, d.m, d.q, d.nbcode, d.col0, d.col1,
                        d.world > 1 ? 1 : 0, d.fpx_r, d.fpx_k, d.fpx_h, d.fpz_r, d.fpz_k, d.fpz_h, d.v, d.U,
-                       d.ldw, d.W, d.ldw, d.binv, d.ldb);
+                       d.ldw, d.W, d.ldw, d.binv, d.ldb, d.rs ? d.rs_r0 : 0, d.rs ? d.rs_r1 : d.m, d.rs);
 }
 
 void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
@@ -708,13 +715,19 @@ void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
     const int kmax = d.k_hint > 0 && d.k_hint < d.m ? d.k_hint : d.m;
     hipLaunchKernelGGL(k_fast_gather_w, dim3((kmax + 15 + 255) / 256, R_), dim3(256), 0, st, d.ctl,
                        d.W, d.ldw, d.drow, d.Wc);
+    // row-sharded basis side: this rank's rows only (a multiple of 16 rows from the top, so the
+    // MFMA tiles are the single-GPU solve's tiles: the same bits)
+    const int r0 = d.rs ? d.rs_r0 : 0, rows = (d.rs ? d.rs_r1 : d.m) - r0;
+    double *binv = d.binv + (long long)r0 * d.ldb;
+    const double *U = d.U + r0;
     static const bool steps = std::getenv("DZG_FLUSH_STEPS") != nullptr; // (A/B switch, tools)
-    if (steps)
-        hipLaunchKernelGGL(k_fast_flush_mfma<false>, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
-                           d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
+    if (rows <= 0) {
+    } else if (steps)
+        hipLaunchKernelGGL(k_fast_flush_mfma<false>, dim3((kmax + 63) / 64, (rows + 63) / 64), dim3(256), 0, st,
+                           d.ctl, rows, binv, d.ldb, U, d.ldw, d.Wc, d.ldw);
     else
-        hipLaunchKernelGGL(k_fast_flush_mfma<true>, dim3((kmax + 63) / 64, (d.m + 63) / 64), dim3(256), 0, st,
-                           d.ctl, d.m, d.binv, d.ldb, d.U, d.ldw, d.Wc, d.ldw);
+        hipLaunchKernelGGL(k_fast_flush_mfma<true>, dim3((kmax + 63) / 64, (rows + 63) / 64), dim3(256), 0, st,
+                           d.ctl, rows, binv, d.ldb, U, d.ldw, d.Wc, d.ldw);
     hipLaunchKernelGGL(k_fast_flush_done, dim3(1), dim3(1), 0, st, d.ctl, ((kmax + 63) / 64) * 64);
 }
 

@@ -15,7 +15,8 @@ static int resolve(int kernel)
 static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
                         const int *plist, const int *nonbasis, const int *var_col, const double *v,
                         double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
-                        double *rz_h, int col0, const int *pcode, hipStream_t st, int rows_T = 0)
+                        double *rz_h, int col0, const int *pcode, hipStream_t st, int rows_T = 0,
+                        int need_kind = -1)
 {
     const dim3 grid(DZG_PRICE_TREE_BLOCKS), block(256);
     const int per_wave = (ncols + 4 * DZG_PRICE_TREE_BLOCKS - 1) / (4 * DZG_PRICE_TREE_BLOCKS);
@@ -30,7 +31,7 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
     const int passes = (per_wave + 15) / 16;
     const int cw = passes > 0 ? (per_wave + passes - 1) / passes : 1;
 #define TREE(CW, DEPTH, TP)                                                                          \
-    hipLaunchKernelGGL((k_price_tree<CW, DEPTH, TP>), grid, block, 0, st, PRICE_ARGS, pcode, rows_T)
+    hipLaunchKernelGGL((k_price_tree<CW, DEPTH, TP>), grid, block, 0, st, PRICE_ARGS, pcode, rows_T, need_kind)
     // (15-16 columns per wave: two passes of 8 with 2-KiB visits, 160.8 us against 162.7 for one pass
     // of 16 at 8192 rows, profiles/r02_price_microbench_adjacent_tiles.txt)
     if (per_wave == 15 || per_wave == 16) { TREE(8, 2, 2); return; }
@@ -58,11 +59,12 @@ static void launch_tree(int ncols, const DzgCtl *ctl, const double *A, long long
 static void launch(int kernel, int ncols, const DzgCtl *ctl, const double *A, long long lda, int m, int q,
                    const int *plist, const int *nonbasis, const int *var_col, const double *v,
                    double *dz, const double *z, const double *zbar, double *rz_r, int *rz_k,
-                   double *rz_h, int col0, const int *pcode, hipStream_t st, int rows_T = 0)
+                   double *rz_h, int col0, const int *pcode, hipStream_t st, int rows_T = 0,
+                   int need_kind = -1)
 {
     if (q <= 0) return;
     if (resolve(kernel) == DZG_PRICE_TREE)
-        launch_tree(ncols, PRICE_ARGS, pcode, st, rows_T);
+        launch_tree(ncols, PRICE_ARGS, pcode, st, rows_T, need_kind);
     else if (resolve(kernel) == DZG_PRICE_WAVE)
         hipLaunchKernelGGL((k_price_wave2<4>), dim3(DZG_PRICE_WAVE_BLOCKS), dim3(256), 0, st, ctl, A,
                            lda, m, q, plist, nonbasis, var_col, v, dz, z, zbar, rz_r, rz_k, rz_h, col0);
@@ -125,7 +127,9 @@ void dzg_launch_transpose_to_rows(const double *A, long long lda, int m, int n, 
 int dzg_price_rows_groups(void) { return PR_GMAX; }
 
 // FAST numerics: structural positions from plist, ratio-test partials for the dual step
-void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
+// need_kind >= 0 (row-sharded ranks, dense, tree / row-wise kernels only): the pass runs only in an
+// iteration of that step kind
+void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind)
 {
     if (d.csc) {
         if (d.spb && d.lcnt && kernel != DZG_PRICE_SEQ) { // sparse basis: the live entries only
@@ -162,15 +166,15 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st)
             // against 92 with four -- tools/price_rows_bench.hip, profiles/r03_price_rows_microbench.txt)
             hipLaunchKernelGGL((k_price_rows<2>), dim3((unsigned)((d.ldt + 511) / 512), PR_GMAX),
                                dim3(256), 0, st, d.ctl, rows_rule, d.At, d.ldt, d.drow, d.bcode, d.vc,
-                               d.ppart);
+                               d.ppart, need_kind);
             hipLaunchKernelGGL(k_price_rows_finish, dim3(DZG_PRICE_TREE_BLOCKS), dim3(256), 0, st,
                                d.ctl, rows_rule, d.ppart, d.ldt, d.q, d.plist, d.pcode, d.nbcode, d.bcode,
-                               d.col0, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, PR_GMAX);
+                               d.col0, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, PR_GMAX, need_kind);
         }
         if (!cols_possible) return;
     }
     launch(kernel, ncols, d.ctl, d.A, d.lda, d.m, d.q, d.plist, d.nbcode, nullptr, d.v, d.dz, d.z,
-           d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, d.pcode, st, rows_T);
+           d.zbar, d.rz_r, d.rz_k, d.rz_h, d.col0, d.pcode, st, rows_T, need_kind);
 }
 
 void dzg_launch_price_raw(int kernel, int m, long long lda, const double *A, const int *cols,

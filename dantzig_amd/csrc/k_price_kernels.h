@@ -379,11 +379,14 @@ __global__ __launch_bounds__(256) void k_price_tree(
     const int *__restrict__ var_col, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
     int *__restrict__ rz_k, double *__restrict__ rz_h, int col0 = 0,
-    const int *__restrict__ pcode = nullptr, int rows_T = 0)
+    const int *__restrict__ pcode = nullptr, int rows_T = 0, int need_kind = -1)
 {
     constexpr int TR = 128;
     if (ctl && ctl->status != DZG_RUNNING) return;
     if (rows_T > 0 && ctl->ncompact < rows_T) return; // the row-wise pass prices this iteration
+    // (row-sharded ranks price a dual step before their second exchange and a primal step after it:
+    // the host enqueues the pass in both places, the one whose step kind it is not returns)
+    if (need_kind >= 0 && ctl->kind != need_kind) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
     const int wg = blockIdx.x * 4 + wave;
@@ -853,20 +856,21 @@ __global__ __launch_bounds__(256) void k_price_csc_rl(
 // = the tree kernel's count of ratio partials.  The order of a column's sum depends on k and the
 // compact numbering only (not on the grid, the tile width or a column sharding).
 // ---------------------------------------------------------------------------------
-#define PR_GMAX 32
-#define PR_BATCH 16 // rows per group at least (G = ceil(rows / PR_BATCH), capped at PR_GMAX)
+#define PR_GMAX DZG_PR_GMAX
+#define PR_BATCH DZG_PR_BATCH // rows per group at least (G = ceil(rows / PR_BATCH), capped at PR_GMAX)
 #define PR_PIPE 8   // rows per register set of the streaming loop
 template <int VEC, int PIPE = PR_PIPE>
 __global__ __launch_bounds__(256) void k_price_rows(
     const DzgCtl *ctl, int rows_T, const double *__restrict__ At, long long ldt,
     const int *__restrict__ drow, const int *__restrict__ bcode, const double *__restrict__ vc,
-    double *__restrict__ part)
+    double *__restrict__ part, int need_kind = -1)
 {
     typedef double vec_t __attribute__((ext_vector_type(2)));
     __shared__ long long s_off[256];
     __shared__ double s_coef[256];
     const int status = ctl->status, k = ctl->ncompact, lp = ctl->leave_pos;
     if (status != DZG_RUNNING || k >= rows_T) return;
+    if (need_kind >= 0 && ctl->kind != need_kind) return; // (see k_price_tree)
     // (the group count follows k alone, so that it -- and with it which rows are this workgroup's --
     // is known after the first trip; the leaving variable's code arrives beside the row list)
     int G = (k + 1 + PR_BATCH - 1) / PR_BATCH;
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(256) void k_price_rows_finish(
     const int *__restrict__ plist, const int *__restrict__ pcode, const int *__restrict__ nbcode,
     const int *__restrict__ bcode, int col0, const double *__restrict__ v, double *__restrict__ dz,
     const double *__restrict__ z, const double *__restrict__ zbar, double *__restrict__ rz_r,
-    int *__restrict__ rz_k, double *__restrict__ rz_h, int gmax)
+    int *__restrict__ rz_k, double *__restrict__ rz_h, int gmax, int need_kind = -1)
 {
     // first trip, side by side: the control block, this thread's position (unit columns) and its
     // first list entry (plist / pcode hold q entries; those beyond nb_struct are stale and only
@@ -980,6 +984,7 @@ __global__ __launch_bounds__(256) void k_price_rows_finish(
     const int count = (int)ctl->nb_struct;
     const double mu = ctl->mu, tau = ctl->tau;
     if (status != DZG_RUNNING || k >= rows_T) return;
+    if (need_kind >= 0 && ctl->kind != need_kind) return;
     int G = (k + 1 + PR_BATCH - 1) / PR_BATCH; // (as k_price_rows)
     G = G > gmax ? gmax : G;
     DzgCand2 best = dzg_cand2_none();

@@ -37,17 +37,21 @@ class ShardedSolver(core.Solver):
     """One rank's share of a column-sharded solve."""
 
     def __init__(self, lp: core.CoreLP, rank: int, world: int, stream: int = 0,
-                 replicate: bool = False, **opts):
+                 replicate: bool = False, shard_rows: bool = False, **opts):
         """replicate=True (dense matrices): every rank keeps all structural columns in its HBM and
-        only the pricing is split, so the exchange records shrink to their headers and the solver
-        can refactorise.  A block LP (CoreLP.from_inequality_block) then takes the other ranks'
-        columns through upload_columns() before the first run."""
+        only the pricing is split, so the exchange records shrink to their headers.  A block LP
+        (CoreLP.from_inequality_block) then takes the other ranks' columns through upload_columns()
+        before the first run.  shard_rows=True (dense matrices): the basis side is sharded too -- a
+        rank owns a block of rows of x, the compact inverse and the eta file, FTRAN / the flush /
+        the update touch those rows only and the x-side candidates travel with their row of the
+        inverse (csrc/k_rowshard.hip); x and xbar are complete on every rank when a run returns."""
         begin, end = col_range(lp.n_struct, rank, world)
         self.rank, self.world = rank, world
         self.col_begin, self.col_end = begin, end
         super().__init__(lp, numerics=core.FAST, rank=rank, world=world, col_begin=begin,
                          col_end=end, stream=stream or None,
-                         replicate_matrix=1 if (replicate and lp.a is not None) else 0, **opts)
+                         replicate_matrix=1 if (replicate and lp.a is not None) else 0,
+                         shard_rows=1 if (shard_rows and lp.a is not None and world > 1) else 0, **opts)
         self.record_doubles = int(_ffi.lib().dzg_shard_record_doubles(self._h))
 
     def upload_columns(self, begin: int, end: int, a_block) -> None:
@@ -104,10 +108,12 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
-def make_lockstep(lp: core.CoreLP, world: int, replicate: bool = False, **opts) -> list:
+def make_lockstep(lp: core.CoreLP, world: int, replicate: bool = False, shard_rows: bool = False,
+                  **opts) -> list:
     """All ranks of a sharded solve inside ONE process on ONE GPU, sharing one stream."""
-    first = ShardedSolver(lp, 0, world, replicate=replicate, **opts)
-    return [first] + [ShardedSolver(lp, r, world, stream=first.stream, replicate=replicate, **opts)
+    first = ShardedSolver(lp, 0, world, replicate=replicate, shard_rows=shard_rows, **opts)
+    return [first] + [ShardedSolver(lp, r, world, stream=first.stream, replicate=replicate,
+                                    shard_rows=shard_rows, **opts)
                       for r in range(1, world)]
 
 
@@ -122,26 +128,35 @@ def run_lockstep(solvers: list, max_new_iters: int = 0) -> str:
 
 # ------------------------------------------------------------------ bench.py, N > 1
 def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, rank, world,
-                     local_rank, replicate: bool) -> dict:
+                     local_rank, replicate: bool, shard_rows: bool = True, warm_k: int = 0) -> dict:
     """One dense G1 workload, column-sharded over `world` ranks.  Every rank generates only its own
     column block (dzg_gen_dense_lp_block: bit-identical to that slice of the whole LP, b and c
     complete), so no process ever holds the whole matrix on the host.  Collective: every rank
     returns.
 
     replicate=False -- the PARTITIONED storage BASELINE.json's north star names: a rank's HBM holds
-    its column block only, the entering column travels in the exchange records (8 m + 64 bytes).
+    its column block only, the entering column travels in the exchange records.
     replicate=True -- every rank also receives the other ranks' blocks (one at a time) and keeps
-    the whole matrix; only the pricing is split and the records are their 64-byte headers."""
+    the whole matrix; only the pricing is split.
+    shard_rows -- the basis side is sharded by rows too (csrc/k_rowshard.hip): FTRAN, the flush and
+    the update divide by the rank count like the pricing pass; False: the round-3 form, the basis
+    side replicated on every rank.
+    warm_k > 0 -- the solve starts from the basis "first warm_k structural columns" (core.warm_started:
+    the deep regime of a solve, reached without the pivots that lead there); the ranks factorise it
+    together at the first run (partitioned: they exchange their basic columns)."""
     begin, end = col_range(cols, rank, world)
     t_gen = time.perf_counter()
     a, b, c = core.gen_dense_lp_block(seed, rows, cols, begin, end)
     lp = core.CoreLP.from_inequality_block(a, b, c, begin, end)
+    if warm_k > 0:
+        lp = core.warm_started(lp, warm_k)
     t_gen = time.perf_counter() - t_gen
     price = {"auto": core.PRICE_AUTO, "seq": core.PRICE_SEQ, "wave": core.PRICE_WAVE,
              "tree": core.PRICE_TREE}[price_name]
     # poll interval 50 divides the default warm-up and step counts: no partial batches
     solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price,
-                           profile=1 << _ffi.K_PRICE, poll_interval=50, replicate=replicate)
+                           profile=1 << _ffi.K_PRICE, poll_interval=50, replicate=replicate,
+                           shard_rows=shard_rows)
     try:
         del a, lp
         # replicated: the other ranks' blocks are generated and uploaded one at a time (host peak:
@@ -160,9 +175,11 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
         nranks = solver.comm_size()
 
         status = "iter_limit"
-        if warmup > 0:
+        t_warm = time.perf_counter()
+        if warmup > 0:  # (a warm start's factorisation happens here, outside the timed region)
             status = solver.run(warmup)
         it0 = solver.poll()[1]          # poll synchronises the stream
+        t_warm = time.perf_counter() - t_warm
         r_warm = solver.result(log=False)
         dist.barrier()
         t0 = time.perf_counter()
@@ -184,10 +201,19 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
             if solver.run(200) in ("iter_limit", "optimal"):
                 rp = solver.result(log=False)
                 n = max(rp.iterations - res.iterations, 1)
-                labels = {"status": "propose first-pivot record", "exchange1": "all-gather 1",
-                          "ftran": "merge + status + FTRAN + BTRAN", "price": "pricing (own columns)",
-                          "ratio": "propose second record", "exchange2": "all-gather 2",
-                          "update": "merge + (dual) FTRAN + pivot + update + flush"}
+                if shard_rows:
+                    labels = {"status": "propose record 1 (z and x first pivots, column, row of the inverse)",
+                              "exchange1": "all-gather 1",
+                              "ftran": "merge + status + (primal) FTRAN on the own rows / (dual) BTRAN row",
+                              "price": "(dual) pricing of the own columns",
+                              "ratio": "propose record 2", "exchange2": "all-gather 2",
+                              "update": "merge + (primal) pricing / (dual) FTRAN on the own rows + books "
+                                        "+ update + flush"}
+                else:
+                    labels = {"status": "propose first-pivot record", "exchange1": "all-gather 1",
+                              "ftran": "merge + status + FTRAN + BTRAN", "price": "pricing (own columns)",
+                              "ratio": "propose second record", "exchange2": "all-gather 2",
+                              "update": "merge + (dual) FTRAN + pivot + update + flush"}
                 mine = torch.tensor([1e3 * (rp.kernel_ms[k] - res.kernel_ms[k]) / n for k in labels],
                                     dtype=torch.float64)
                 worst = mine.clone()
@@ -214,24 +240,33 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"dense random LP {rows}x{cols} fp64, generator G1 seed {seed}, "
-                        f"column-sharded over {world} GPUs",
+                        f"column-sharded over {world} GPUs"
+                        + (f", warm-started from a basis of {warm_k} structural columns" if warm_k else ""),
             "numerics": "fast", "price_kernel": price_name,
             "status_after_timed_region": status, "requested_steps": steps,
-            "exchanges_per_iteration": 2, "record_bytes": record_bytes,
-            "matrix": ("replicated on every rank (pricing split by column block; 64-byte records)"
+            "k_at_start": r_warm.dense_columns, "k_at_end": res.dense_columns,
+            "exchanges_per_iteration": 2, "record_bytes_max": record_bytes,
+            "matrix": ("replicated on every rank (pricing split by column block)"
                        if replicate else
                        "partitioned by column block (a rank holds its block only; the entering "
                        "column travels in the exchange records)"),
+            "basis_side": ("sharded by rows (a rank owns m / N rows of x, the compact inverse and the eta "
+                           "file; x-side candidates travel with their row of the inverse)" if shard_rows
+                           else "replicated on every rank"),
             "collective": "ncclAllGather (RCCL) of one record per rank",
             "nranks_ncclCommCount": nranks,
             "lp_generation_s": round(t_gen, 3),
+            "warmup_s_including_any_factorisation": round(t_warm, 3),
+            "refactors": res.refactors,
             "max_pivot_error": res.max_pivot_error,
         },
         "roofline": {
             "bound": "hbm",
             "kernel": "pricing pass of rank 0 over its column block: row-wise (k_price_rows + "
                       "k_price_rows_finish) while k < 0.93 m n_s / (n_s + m), k_price_tree beyond; "
-                      "k = %d at the end of the timed region" % res.dense_columns,
+                      "k = %d at the end of the timed region%s" % (
+                          res.dense_columns, " (dual steps only: a primal step of a row-sharded rank "
+                                             "prices inside its last phase)" if shard_rows else ""),
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": None, "avg_launch_us": 1e3 * d_ms / max(d_launch, 1),
         },
@@ -239,6 +274,9 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
         "phases": phases,
         "pricing_bytes_all_ranks": float(pb.item()),
     }
+
+
+DEEP = {"rows": 32768, "cols": 65536, "seed": 1005, "warm_k": 16384, "steps": 300, "warmup": 50}
 
 
 def bench_main(args, rank: int, world: int, local_rank: int) -> int:
@@ -258,28 +296,42 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
     _ffi.require_gpu()
     # gloo: bootstrap (ncclUniqueId) + barriers only; a rank that dies must not hang the others
     dist.init_process_group("gloo", rank=rank, world_size=world,
-                            timeout=datetime.timedelta(seconds=600))
+                            timeout=datetime.timedelta(seconds=900))
     # `value`: the PARTITIONED storage mode, the one BASELINE.json's north star states ("constraint
-    # matrix column-block partitioned across the 8 GPUs"); "replicated": the same workload with the
-    # whole matrix in every rank's HBM (it fits: 1 GB / 17 GB of 288) and header-only records.
+    # matrix column-block partitioned across the 8 GPUs"), the basis side sharded by rows (round 4);
+    # "replicated": the same workload with the whole matrix in every rank's HBM (it fits: 1 GB / 17
+    # GB of 288); "basis_replicated": the round-3 form (every rank streams the whole inverse).
     sub = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "phases")
-    out = _measure_sharded(dist, torch, args.rows, args.cols, args.seed, args.price, args.steps,
-                           args.warmup, rank, world, local_rank, replicate=False)
-    rep = _measure_sharded(dist, torch, args.rows, args.cols, args.seed, args.price, args.steps,
-                           args.warmup, rank, world, local_rank, replicate=True)
+
+    def run(rows, cols, seed, steps, warmup, **kw):
+        return _measure_sharded(dist, torch, rows, cols, seed, args.price, steps, warmup, rank, world,
+                                local_rank, **kw)
+
+    out = run(args.rows, args.cols, args.seed, args.steps, args.warmup, replicate=False)
+    rep = run(args.rows, args.cols, args.seed, args.steps, args.warmup, replicate=True)
     out["replicated"] = {k: rep[k] for k in sub}
+    old = run(args.rows, args.cols, args.seed, args.steps, args.warmup, replicate=False, shard_rows=False)
+    out["basis_replicated"] = {k: old[k] for k in sub}
     profiled = ("ROCP_TOOL_LIBRARIES" in os.environ
                 or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))
-    if (args.rows == 8192 and args.cols == 16384 and not getattr(args, "no_secondary", False)
-            and not profiled):
+    default_workload = (args.rows == 8192 and args.cols == 16384
+                        and not getattr(args, "no_secondary", False) and not profiled)
+    if default_workload:
         # config 5: the LP the north star's 8-GPU target is quoted on (bench.py reports the same
-        # workload on one GPU under the same key), both storage modes again
-        sec = _measure_sharded(dist, torch, 32768, 65536, 1005, "auto", 300, 50, rank, world,
-                               local_rank, replicate=False)
+        # workload on one GPU under the same key), from the slack basis ...
+        sec = run(32768, 65536, 1005, 300, 50, replicate=False)
         out["secondary"] = {k: sec[k] for k in sub}
-        sec = _measure_sharded(dist, torch, 32768, 65536, 1005, "auto", 300, 50, rank, world,
-                               local_rank, replicate=True)
-        out["secondary"]["replicated"] = {k: sec[k] for k in sub}
+        # ... and DEEP in its solve, where sharding is meant to pay: warm-started from a basis of
+        # 16 384 structural columns (the compact inverse is 4.3 GB, a pricing pass 8.6 GB: bench.py's
+        # one-GPU line carries the same block), against the round-3 form on the same state.
+        # (Partitioned storage only at this size: a replicated run has every rank generate all 17 GB.)
+        dp = DEEP
+        deep = run(dp["rows"], dp["cols"], dp["seed"], dp["steps"], dp["warmup"], replicate=False,
+                   warm_k=dp["warm_k"])
+        out["deep"] = {k: deep[k] for k in sub}
+        deep = run(dp["rows"], dp["cols"], dp["seed"], dp["steps"], dp["warmup"], replicate=False,
+                   shard_rows=False, warm_k=dp["warm_k"])
+        out["deep"]["basis_replicated"] = {k: deep[k] for k in sub}
     if rank == 0 and not getattr(args, "no_cpu_baseline", False):
         # the reference's algorithm on this box's host, one core, while the other ranks wait at the
         # barrier below (bench.py: cpu_baseline)

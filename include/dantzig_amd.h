@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DZG_ABI_VERSION 3
+#define DZG_ABI_VERSION 4
 
 /* Outcome codes.  0..2 mirror the reference: Ok / Error::Unbounded / Error::Infeasible
  * (src/error.rs:3-7, src/simplex.rs:313,325).  The rest do not exist in the
@@ -169,6 +169,17 @@ typedef struct {
                                  numerics with near ties counted, and the result says so
                                  (near_ties > 0, numerics_used = FAST).  0 = default (600 s),
                                  < 0 = no limit */
+    int32_t shard_rows;       /* column sharding, dense: 1 = the BASIS SIDE is sharded too -- rank r owns
+                                 the rows [r S, (r+1) S), S = ceil4(ceil(m / world)), of x, xbar, dx, of
+                                 the compact inverse Binv0 and of the eta columns U; FTRAN, the x-side
+                                 ratio test, the eta flush and the update touch a rank's own rows only
+                                 (8 m k / world bytes per FTRAN instead of 8 m k on every rank).  Row p of
+                                 the inverse (BTRAN) lives on one rank: every x-side candidate travels
+                                 with its row in the exchange records (layout below), still two exchanges
+                                 per iteration.  x / xbar are complete on every rank whenever
+                                 dzg_shard_run / dzg_shard_run_lockstep return.  FAST numerics, pricing
+                                 AUTO or TREE.  0 (default): the basis side is replicated on every rank */
+    int32_t reserved0;
 } dzg_opts;
 
 /* What FAST numerics does at a near tie (the pivot rule is a first-wins strict argmax,
@@ -238,6 +249,20 @@ typedef struct {
     int64_t chain_fallbacks; /* three-launch iteration: device-wide barriers that failed (another
                                 kernel held CUs or LDS of the device) and were recovered from by
                                 running on without barriers; 0 on an undisturbed device            */
+    int32_t price_pass_used; /* FAST, dense matrix: which pricing pass the executed pivots ran, a bit
+                                mask: 1 = row-wise over the k + 1 rows v does not zero (k_price_rows),
+                                2 = column-wise over every nonbasic column (k_price_tree / the kernel
+                                opts.price_kernel names); 3 = both (k crossed the rule's threshold);
+                                0 = no pivot executed, or STRICT / CSC input                       */
+    int32_t price_rows_copy; /* 1: the row-major copy of the matrix the row-wise pass streams is
+                                resident; 0: not kept -- an explicit price_kernel, CSC, STRICT,
+                                DZG_PRICE_ROWS=0, or hipMalloc could not hold a second copy of the
+                                matrix (the solve then prices column-wise throughout: same pivots,
+                                more bytes early in the solve)                                     */
+    double state_drift;      /* FAST: largest relative difference between the carried x_B / z_N and
+                                their recomputation from the fresh inverse, measured at the last
+                                refactorisation (0 if none): what the near-tie tolerance is widened
+                                by (tau = max(tie_tol, 64 max_pivot_error, 4 state_drift))         */
 } dzg_result;
 
 typedef struct dzg_solver dzg_solver;
@@ -421,6 +446,17 @@ typedef struct {
  * phase3: merges, finishes the step (dual: FTRAN), pivots and updates.
  * `send`/`recv` are DEVICE pointers owned by the host (recv holds world records in rank order).
  * The library never calls a collective itself. */
+/* With opts.shard_rows the record is
+ *   [0..7]   the z-side candidate as above ([7] reserved)
+ *   [8] ratio  [9] basis position p (-1 = none)  [10] x_p  [11] xbar_p  [12] dx_p (second exchange of
+ *            a primal step)  [13] reserved  [14] runner-up  [15] reserved      -- the x-side candidate
+ *            of the rank's own rows: first pivot (exchange 1), ratio test of a primal step (exchange 2)
+ *   [16 .. 80)          U_t[p] of the pending etas t < 64
+ *   [80 .. 80 + mc)     the z-side candidate's column of A (mc = ceil16(m); partitioned storage only,
+ *                       mc = 0 with replicate_matrix)
+ *   [80 + mc .. )       row p of the compact inverse Binv0, as many entries as the record holds
+ * dzg_shard_record_doubles is the largest record (room for a row of m entries); dzg_shard_run sends
+ * what the current compact width needs. */
 int64_t dzg_shard_record_doubles(const dzg_solver *s);
 int dzg_shard_phase1(dzg_solver *s, double *send_dev);
 int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *send_dev);

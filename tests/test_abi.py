@@ -32,7 +32,7 @@ def test_symbol_is_exported(name):
 
 def test_abi_version_and_status_strings():
     lib = _ffi.lib()
-    assert lib.dzg_abi_version() == 3
+    assert lib.dzg_abi_version() == 4
     assert _ffi.status_str(0) == "optimal" and _ffi.status_str(1) == "unbounded"
     assert _ffi.status_str(2) == "infeasible" and _ffi.status_str(-1) == "device_error"
     assert _ffi.status_str(7) == "near_tie"
@@ -240,7 +240,7 @@ def test_plain_c_host_links_and_fails_loudly_without_gpu(tmp_path):
         pytest.skip("a GPU is visible: covered by the gpu-marked variant")
     run = _build_c_host(tmp_path)
     assert run.returncode == 3
-    assert "abi 3 devices 0" in run.stdout
+    assert "abi 4 devices 0" in run.stdout
     assert "device_error" in run.stderr and "no CPU path" in run.stderr
 
 

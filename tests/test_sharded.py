@@ -539,3 +539,109 @@ def test_sharded_warm_start_from_a_non_slack_basis(replicate):
         assert res.refactors == 1
         assert res.pivots == cont.pivots and np.array_equal(res.x, cont.x)
         assert res.objective == cont.objective and np.array_equal(res.basis, cont.basis)
+
+
+# ------------------------------------------------------------------ row-sharded basis side
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,replicate", [(2, False), (3, True), (4, False), (8, True), (8, False)])
+def test_row_sharded_solve_is_bit_identical_to_the_unsharded_one(world, replicate):
+    """opts.shard_rows (csrc/k_rowshard.hip): rank r owns a block of ROWS of x, xbar, dx, the compact
+    inverse and the eta columns as well as its block of columns; FTRAN, the x-side ratio test, the
+    flush and the update touch those rows only, and an x-side candidate travels with its row of the
+    inverse.  Same two exchanges, the same computation: the oracle's pivot log, and the single-GPU
+    solve's mu of every pivot, x, xbar, basis, objective and monitor bit for bit -- partitioned and
+    replicated matrix storage, row slices that leave some ranks without rows (8 ranks, 160 rows:
+    slices of 32)."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+
+    a, b, c = core.gen_dense_lp(seed=43, m=160, n_struct=420)
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    single = core.solve(lp, numerics=core.FAST, poll_interval=16)
+    solvers = make_lockstep(lp, world, replicate=replicate, shard_rows=True, poll_interval=16)
+    try:
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == want.status == "optimal"
+    for res in results:
+        assert [(k, e, l) for k, e, l, _ in res.pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
+        assert res.pivots == single.pivots                      # mu of every pivot included
+        assert np.array_equal(res.x, single.x) and np.array_equal(res.xbar, single.xbar)
+        assert np.array_equal(res.basis, single.basis) and res.objective == single.objective
+        assert res.max_pivot_error == single.max_pivot_error and res.min_margin == single.min_margin
+        assert res.near_ties == single.near_ties
+
+
+@pytest.mark.gpu
+def test_row_sharded_on_integer_lps_and_terminal_verdicts():
+    """Ties, zero pivots, unbounded and infeasible verdicts, near-tie bookkeeping: 40 small-integer
+    and 0/1 LPs (and continuous ones) row-sharded over 3 ranks against the single-GPU FAST solve --
+    status, pivot log with mu, near-tie record, bit for bit."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+    from tests.lp_families import make_lp
+
+    seen = set()
+    for seed in range(9500, 9540):
+        a, b, c = make_lp(seed, seed % 3, 3, 50)
+        lp = core.CoreLP.from_inequality_form(a, b, c)
+        single = core.solve(lp, numerics=core.FAST, poll_interval=8, max_iter=3000)
+        solvers = make_lockstep(lp, 3, shard_rows=True, replicate=bool(seed & 1), poll_interval=8,
+                                max_iter=3000)
+        try:
+            status = run_lockstep(solvers)
+            results = [s.result() for s in solvers]
+        finally:
+            for s in solvers:
+                s.close()
+        seen.add(status)
+        for res in results:
+            assert (res.status, res.pivots) == (single.status, single.pivots), seed
+            assert (res.near_ties, res.first_near_tie, res.min_margin) == \
+                (single.near_ties, single.first_near_tie, single.min_margin), seed
+            assert np.array_equal(res.x, single.x), seed
+    assert {"optimal", "unbounded", "infeasible"} <= seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("replicate", [False, True])
+def test_row_sharded_whole_solve_with_refactorisation_and_resume(replicate):
+    """BASELINE config 2 (1024 x 2048), 4 row-sharded ranks: a refactorisation every 3 000 pivots
+    (partitioned: the ranks exchange their basic columns), the solve cut into budgeted runs (7 000 pivots each: x and
+    xbar are gathered at every return and the rows' owners carry on from their own copies), the
+    row-wise pricing pass and -- beyond k = rows_T -- the column pass, both re-derived for the
+    entering column by every rank in a primal step: the oracle's 21 642 pivots, and the single-GPU
+    solve with the same refactorisations bit for bit."""
+    from dantzig_amd import core
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_pivots_1002_1024x2048.npz"))
+    a, b, c = core.gen_dense_lp(seed=int(fx["seed"]), m=int(fx["m"]), n_struct=int(fx["n_struct"]))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    single = core.solve(lp, numerics=core.FAST, poll_interval=50, refactor_interval=3000)
+    assert single.price_pass_used == 3          # (k crosses the rule's threshold in this solve)
+    solvers = make_lockstep(lp, 4, replicate=replicate, shard_rows=True, poll_interval=50,
+                            refactor_interval=3000)
+    try:
+        status, runs = "iter_limit", 0
+        while status == "iter_limit":
+            status = run_lockstep(solvers, 7000)
+            runs += 1
+            mid = [s.result(log=False) for s in solvers]
+            assert all(np.array_equal(r.x, mid[0].x) and np.array_equal(r.xbar, mid[0].xbar) for r in mid)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == "optimal" and runs == 4
+    for res in results:
+        assert res.iterations == int(fx["iterations"])
+        assert np.array_equal(np.array([p[1] for p in res.pivots]), fx["entering"])
+        assert np.array_equal(np.array([p[2] for p in res.pivots]), fx["leaving"])
+        assert res.refactors == single.refactors >= 6
+        assert res.pivots == single.pivots and np.array_equal(res.x, single.x)
+        assert res.objective == single.objective and res.max_pivot_error == single.max_pivot_error
