@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libdantzig_amd.so")
 ARCH = "gfx950"
-SOURCES = ["engine.hip", "k_vector.hip", "k_price.hip", "k_strict.hip", "k_fast.hip", "k_chain.hip", "k_sparse.hip", "k_refactor.hip", "k_rowshard.hip",
+SOURCES = ["engine.hip", "k_vector.hip", "k_price.hip", "k_strict.hip", "k_fast.hip", "k_chain.hip", "k_sparse.hip", "k_refactor.hip", "k_rowshard.hip", "k_drift.hip",
            "model.cpp", "lpgen.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-result", "-Wno-unused-value"]

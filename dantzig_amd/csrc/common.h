@@ -84,6 +84,8 @@ struct DzgCtl {
                           // exchange 2: primal step)
     int price_mask;       // pricing passes the executed pivots ran: 1 row-wise, 2 column-wise
     double dxp;
+    double drift_tau;     // 4 x the relative drift of the carried x, xbar, z against the fresh inverse
+                          // at the last refactorisation (k_drift.hip); part of tau
     unsigned long long bar_gen; // device-wide barriers passed so far (k_chain.hip)
 };
 
@@ -496,6 +498,13 @@ void dzg_launch_rs_books(const DzgDev &d, const double *xrecv1, hipStream_t st);
 void dzg_launch_rs_lockstep_gather(double *const *ptrs, int world, int m, int slice, hipStream_t st);
 void dzg_launch_rs_pack(const DzgDev &d, int slice, double *send, hipStream_t st);
 void dzg_launch_rs_unpack(const DzgDev &d, int slice, const double *recv, hipStream_t st);
+
+// k_drift.hip: carried state against the fresh inverse, at a refactorisation
+void dzg_launch_drift(const DzgDev &d, const double *b0, const double *xb0, const double *cdev,
+                      double *agb, double *agx, double *part, double *y, double *dzy, double *out,
+                      int k_bound, hipStream_t st);
+int dzg_drift_blocks(void);
+int dzg_drift_chunks(void);
 
 // k_sparse.hip
 void dzg_launch_sp_init(const DzgDev &d, int first, hipStream_t st);

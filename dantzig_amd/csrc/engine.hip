@@ -97,7 +97,7 @@ struct dzg_solver {
     // refactorisation workspace (FAST, opts.refactor_interval != 0)
     double *rfG = nullptr, *rfX = nullptr, *rfPn = nullptr, *rfTri = nullptr; // (rfPn: one 64-column panel,
                                                                  // column-major; rfTri: L11^-1, U11^-1 per panel)
-    long long rf_ld = 0;
+    long long rf_ld = 0, rf_rows = 0; // leading dimension and rows of rfG / rfX as allocated
     int *rf_piv = nullptr, *rf_spos = nullptr, *rf_scode = nullptr, *rf_lpos = nullptr,
         *rf_lrow = nullptr, *rf_counts = nullptr, *rf_lslot = nullptr;
     long long since_refactor = 0;
@@ -118,6 +118,10 @@ struct dzg_solver {
     double max_err_life = 0.0; // largest ctl->max_pivot_err ever read (the device value restarts
                                // at every refactorisation)
     double state_drift = 0.0;  // carried x_B / z_N against the fresh inverse, at the last refactorisation
+    // k_drift.hip: the data the state is recomputed from (solves that start on the slack basis of a
+    // dense matrix on one GPU; nullptr otherwise) and scratch
+    double *dr_b0 = nullptr, *dr_xb0 = nullptr, *dr_c = nullptr, *dr_agb = nullptr, *dr_agx = nullptr,
+           *dr_part = nullptr, *dr_y = nullptr, *dr_dzy = nullptr, *dr_out = nullptr;
     // FAST, dense, one GPU: the three-launch chain (k_chain.hip)
     unsigned long long *chain_bar = nullptr; // barrier counters (cleared only by chain_recover)
     unsigned long long *chain_dbg = nullptr; // DZG_CHAIN_DEBUG=1: phase clocks of workgroup 0
@@ -609,11 +613,29 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
             s->opts.refactor_interval = o.refactor_interval;
         }
         const bool needs_initial_refactor = !slack_basis && !s->pending_refactor;
+        if (slack_basis && d.world == 1 && !d.csc && m > 0 && q > 0) {
+            // the state a refactorisation can be checked against (k_drift.hip): b = the starting x,
+            // xbar0 = the starting xbar, c
+            TRY(dev_alloc(s, &s->dr_b0, (size_t)m + 2)); TRY(dev_alloc(s, &s->dr_xb0, (size_t)m + 2));
+            TRY(dev_alloc(s, &s->dr_c, (size_t)n));
+            HIP_OK(hipMemcpyAsync(s->dr_b0, lp->x, sizeof(double) * m, hipMemcpyHostToDevice, s->st));
+            HIP_OK(hipMemcpyAsync(s->dr_xb0, lp->xbar ? lp->xbar : ones.data(), sizeof(double) * m,
+                                  hipMemcpyHostToDevice, s->st));
+            HIP_OK(hipMemcpyAsync(s->dr_c, lp->c, sizeof(double) * n, hipMemcpyHostToDevice, s->st));
+        }
         // row stride: not a multiple of a large power of two, so that the first k columns of
         // consecutive rows do not all land on the same HBM channels
         d.ldb = ((long long)m + 15) / 16 * 16 + 32;
         d.ldw = ((long long)m + 15) / 16 * 16 + 64;
-        TRY(dev_alloc(s, &d.binv, (size_t)(m ? m : 1) * (size_t)d.ldb));
+        {
+            // a row-sharded basis side keeps its own rows of Binv0 only; the kernels address rows by
+            // their global index, so d.binv points rs_r0 rows BEFORE the allocation (never
+            // dereferenced outside [rs_r0, rs_r1): every kernel that touches Binv0 takes the range)
+            const size_t rows_kept = d.rs ? (size_t)(d.rs_r1 - d.rs_r0) : (size_t)m;
+            double *binv_alloc = nullptr;
+            TRY(dev_alloc(s, &binv_alloc, (rows_kept ? rows_kept : 1) * (size_t)d.ldb));
+            d.binv = binv_alloc - (d.rs ? (long long)d.rs_r0 * d.ldb : 0);
+        }
         TRY(dev_alloc(s, &d.drow, (size_t)m)); TRY(dev_alloc(s, &d.dslot, (size_t)m));
         TRY(dev_alloc(s, &d.U, (size_t)d.ldw * DZG_RMAX));
         TRY(dev_alloc(s, &d.W, (size_t)d.ldw * DZG_RMAX));
@@ -897,19 +919,43 @@ static int read_ctl(dzg_solver *s)
 // drifts never pays for it, and one that does can still recover.
 static int refactor_workspace(dzg_solver *s)
 {
-    if (s->rfG) return 0;
+    if (s->rf_piv) return 0;
     const size_t m = (size_t)(s->d.m ? s->d.m : 1);
     s->rf_ld = ((long long)s->d.m + 15) / 16 * 16 + 16;
-    double *g = nullptr;
-    TRY(dev_alloc(s, &g, m * (size_t)s->rf_ld));
-    TRY(dev_alloc(s, &s->rfX, m * (size_t)s->rf_ld));
     TRY(dev_alloc(s, &s->rfPn, (size_t)64 * (size_t)s->rf_ld));
     TRY(dev_alloc(s, &s->rfTri, ((m + 63) / 64) * (size_t)(2 * 64 * 64)));
-    TRY(dev_alloc(s, &s->rf_piv, m)); TRY(dev_alloc(s, &s->rf_spos, m));
+    TRY(dev_alloc(s, &s->rf_spos, m));
     TRY(dev_alloc(s, &s->rf_scode, m)); TRY(dev_alloc(s, &s->rf_lpos, m));
     TRY(dev_alloc(s, &s->rf_lrow, m)); TRY(dev_alloc(s, &s->rf_counts, 4));
     TRY(dev_alloc(s, &s->rf_lslot, m));
-    s->rfG = g; // set last: rfG != nullptr means "workspace complete"
+    TRY(dev_alloc(s, &s->rf_piv, m)); // set last: rf_piv != nullptr means "lists reserved"
+    return 0;
+}
+
+// The two big panels G and X hold k x k (the structural block, its factors, the inverse) and then
+// nl x k (the basic-slack rows A[L, S]): max(k, nl) rows of rf_ld doubles each -- half of m x m when
+// the basis is half structural, which is what lets eight ranks of config 5 share one device in the
+// lockstep harness.  They grow when a later basis needs more rows.
+static int refactor_panels(dzg_solver *s, int k, int nl)
+{
+    const long long need = k > nl ? k : nl;
+    if (s->rfG && s->rf_rows >= need) return 0;
+    for (double **p : {&s->rfG, &s->rfX})
+        if (*p) {
+            auto it = std::find(s->allocs.begin(), s->allocs.end(), (void *)*p);
+            if (it != s->allocs.end()) s->allocs.erase(it);
+            HIP_OK(hipFree(*p));
+            *p = nullptr;
+        }
+    long long rows = need + need / 8 + 64; // (head room: k moves by one per pivot)
+    if (rows > s->d.m) rows = s->d.m;
+    if (rows < 1) rows = 1;
+    double *x = nullptr, *g = nullptr;
+    TRY(dev_alloc(s, &x, (size_t)rows * (size_t)s->rf_ld));
+    TRY(dev_alloc(s, &g, (size_t)rows * (size_t)s->rf_ld));
+    s->rfX = x;
+    s->rfG = g;
+    s->rf_rows = rows;
     return 0;
 }
 
@@ -932,6 +978,7 @@ static int refactor_stage_a(dzg_solver *s, int counts[2], bool *active)
     if (!*active) return 0;
     if (counts[0] != s->h_ctl->ncompact)
         return fail(DZG_E_DEVICE, "refactor: structural basics != dense columns");
+    TRY(refactor_panels(s, counts[0], counts[1]));
     dzg_launch_refactor_a(d, counts[0], s->rfG, s->rfX, s->rf_ld, s->rf_scode, s->rf_counts + 2, s->st);
     return 0;
 }
@@ -972,6 +1019,46 @@ static int shard_sum(dzg_solver *s, double *buf, size_t count)
     return 0;
 }
 
+// The carried x, xbar, z against their recomputation from the inverse the refactorisation has just
+// built (k_drift.hip); the result widens the near-tie tolerance and is reported as state_drift.
+static int measure_drift(dzg_solver *s)
+{
+    if (!s->dr_b0 || s->d.world != 1 || s->d.spb) return 0;
+    DzgDev &d = s->d;
+    if (!s->dr_out) {
+        TRY(dev_alloc(s, &s->dr_agb, (size_t)d.m + 2)); TRY(dev_alloc(s, &s->dr_agx, (size_t)d.m + 2));
+        TRY(dev_alloc(s, &s->dr_part, (size_t)dzg_drift_chunks() * (size_t)d.ldw));
+        TRY(dev_alloc(s, &s->dr_y, (size_t)d.m + 2)); TRY(dev_alloc(s, &s->dr_dzy, (size_t)d.q));
+        TRY(dev_alloc(s, &s->dr_out, (size_t)6 * dzg_drift_blocks()));
+    }
+    dzg_launch_drift(d, s->dr_b0, s->dr_xb0, s->dr_c, s->dr_agb, s->dr_agx, s->dr_part, s->dr_y, s->dr_dzy,
+                     s->dr_out, (int)s->h_ctl->ncompact, s->st);
+    const int nb = dzg_drift_blocks();
+    std::vector<double> out((size_t)6 * nb);
+    HIP_OK(hipMemcpyAsync(out.data(), s->dr_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, s->st));
+    HIP_OK(hipStreamSynchronize(s->st));
+    double e[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nb; ++b) {
+        for (int j = 0; j < 4; ++j) e[j] = std::max(e[j], out[(size_t)4 * b + j]);
+        for (int j = 0; j < 2; ++j) e[4 + j] = std::max(e[4 + j], out[(size_t)4 * nb + 2 * b + j]);
+    }
+    double drift = 0.0;
+    for (int j = 0; j < 6; j += 2) {
+        const double rel = e[j] / std::max(1.0, e[j + 1]);
+        if (rel == rel && rel > drift) drift = rel;
+    }
+    s->state_drift = drift;
+    DzgCtl *h = s->h_ctl;
+    h->drift_tau = 4.0 * drift;
+    HIP_OK(hipMemcpyAsync(&d.ctl->drift_tau, &h->drift_tau, sizeof(double), hipMemcpyHostToDevice, s->st));
+    if (h->tie_tol >= 0.0) { // (the monitor restarted with the fresh inverse: max_pivot_err = 0)
+        h->tau = std::max(h->tie_tol, h->drift_tau);
+        HIP_OK(hipMemcpyAsync(&d.ctl->tau, &h->tau, sizeof(double), hipMemcpyHostToDevice, s->st));
+    }
+    HIP_OK(hipStreamSynchronize(s->st));
+    return 0;
+}
+
 static int refactor_now(dzg_solver *s)
 {
     if (partitioned(s) && s->in_lockstep)
@@ -986,7 +1073,8 @@ static int refactor_now(dzg_solver *s)
     double *block = nullptr;
     TRY(refactor_stage_b(s, counts, &block));
     if (partitioned(s) && block) TRY(shard_sum(s, block, (size_t)counts[1] * (size_t)s->rf_ld));
-    return refactor_stage_c(s, counts);
+    TRY(refactor_stage_c(s, counts));
+    return measure_drift(s);
 }
 
 // All ranks of a lockstep group (one process, one device, one stream) refactorise together; the

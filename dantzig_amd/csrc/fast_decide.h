@@ -92,7 +92,7 @@ __device__ __forceinline__ bool fast_status(DzgCtl *ctl, DzgCtl &c, bool lead,
         // tolerance when `top` is within eps/2 of it, or within what the health monitor says
         // FAST's rounding amounts to (a degenerate optimum has top = 0 up to that rounding
         // in FAST and exactly in the reference: both sides of the test agree)
-        const double noise = 64.0 * c.max_pivot_err;
+        const double noise = 64.0 * c.max_pivot_err > c.drift_tau ? 64.0 * c.max_pivot_err : c.drift_tau;
         const double tau_opt = noise > 0.5 * eps ? noise : 0.5 * eps;
         margin = fabs(top - eps) > tau_opt ? inf : 0.0;
         if (c.tie_tol < 0.0) margin = inf;

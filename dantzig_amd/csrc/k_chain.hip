@@ -658,7 +658,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
         wzero = cj < 0 ? -1 - cj : -1;
         rdxp = 1.0 / dxp;
         if (c.tie_tol >= 0.0) { // the tolerance the books are setting
-            const double adaptive = 64.0 * ps.max_err;
+            double adaptive = 64.0 * ps.max_err;
+            if (c.drift_tau > adaptive) adaptive = c.drift_tau;
             tau = adaptive > c.tie_tol ? adaptive : c.tie_tol;
         }
         ts.mark(slot); // primal 1 / dual 4: step lengths

@@ -652,7 +652,11 @@ __global__ __launch_bounds__(256) void k_shard_scatter_col(const DzgCtl *ctl, in
 // ---------------------------------------------------------------------------------
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
 {
-    hipMemsetAsync(d.binv, 0, sizeof(double) * (size_t)d.m * (size_t)d.ldb, st);
+    {
+        const int r0 = d.rs ? d.rs_r0 : 0, rows = (d.rs ? d.rs_r1 : d.m) - r0;
+        if (rows > 0)
+            hipMemsetAsync(d.binv + (long long)r0 * d.ldb, 0, sizeof(double) * (size_t)rows * (size_t)d.ldb, st);
+    }
     hipMemsetAsync(d.U, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.W, 0, sizeof(double) * (size_t)d.ldw * R_, st);
     hipMemsetAsync(d.Wc, 0, sizeof(double) * (size_t)d.ldw * R_, st);

@@ -42,12 +42,20 @@ template <bool ZERO_C>
 __global__ __launch_bounds__(256) void k_ref_gemm(int M, int N, int K, const double *__restrict__ A,
                                                   long long lda, const double *__restrict__ B,
                                                   long long ldb, double *__restrict__ C,
-                                                  long long ldc, const int *__restrict__ crow)
+                                                  long long ldc, const int *__restrict__ crow,
+                                                  int crow0 = 0, int crow1 = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64;
     const int i0 = (blockIdx.y * 4 + wave) * 16;
     if (c0 >= N || i0 >= M) return;
+    // (crow0, crow1) != (0, 0) (a row-sharded basis side): only the rows of C in [crow0, crow1) exist on this
+    // device; crow ascends, so a strip whose first and last target lie outside has nothing to do
+    const bool ranged = crow && !(crow0 == 0 && crow1 == 0); // (0, 0): every row
+    if (ranged) {
+        const int first = crow[i0], last = crow[i0 + 15 < M ? i0 + 15 : M - 1];
+        if (last < crow0 || first >= crow1) return;
+    }
     const int li = lane & 15, lk = lane >> 4;
     double4_t acc[4];
 #pragma unroll
@@ -80,7 +88,10 @@ __global__ __launch_bounds__(256) void k_ref_gemm(int M, int N, int K, const dou
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
-            if (row < M && col < N) C[(long long)(crow ? crow[row] : row) * ldc + col] = acc[j][g];
+            if (row < M && col < N) {
+                const int cr = crow ? crow[row] : row;
+                if (!ranged || (cr >= crow0 && cr < crow1)) C[(long long)cr * ldc + col] = acc[j][g];
+            }
         }
     }
 }
@@ -104,13 +115,23 @@ typedef double double2r_t __attribute__((ext_vector_type(2)));
 template <bool ZERO_C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ref_gemm_lds(
     int M, int N, int K, const double *__restrict__ A, long long lda, const double *__restrict__ B,
-    long long ldb, double *__restrict__ C, long long ldc, const int *__restrict__ crow)
+    long long ldb, double *__restrict__ C, long long ldc, const int *__restrict__ crow,
+    int crow0 = 0, int crow1 = 0)
 {
     __shared__ __attribute__((aligned(16))) double s_b[GKC][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * 64;
     const int i0 = (blockIdx.y * 4 + wave) * 16;
     const int li = lane & 15, lk = lane >> 4;
+    // (see k_ref_gemm; the test is on the WORKGROUP's 64 rows: the barriers below stay uniform)
+    const bool ranged = crow && !(crow0 == 0 && crow1 == 0); // (0, 0): every row
+    if (ranged) {
+        const int b0 = blockIdx.y * 64;
+        if (b0 < M) {
+            const int first = crow[b0], last = crow[b0 + 63 < M ? b0 + 63 : M - 1];
+            if (last < crow0 || first >= crow1) return;
+        }
+    }
     double4_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -166,7 +187,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
-            if (row < M && col < N) C[(long long)(crow ? crow[row] : row) * ldc + col] = acc[j][g];
+            if (row < M && col < N) {
+                const int cr = crow ? crow[row] : row;
+                if (!ranged || (cr >= crow0 && cr < crow1)) C[(long long)cr * ldc + col] = acc[j][g];
+            }
         }
     }
 }
@@ -908,12 +932,14 @@ __global__ __launch_bounds__(256) void k_ref_colperm(int k, const double *__rest
 // Binv0[spos[b]][a] = X[b][a]   grid (ceil(k/256), k)
 __global__ __launch_bounds__(256) void k_ref_scatter(int k, const double *__restrict__ X,
                                                      long long ldx, const int *__restrict__ spos,
-                                                     double *__restrict__ binv, long long ldb)
+                                                     double *__restrict__ binv, long long ldb,
+                                                     int row0, int row1)
 {
     const int b = blockIdx.y;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= k) return;
-    binv[(long long)spos[b] * ldb + a] = X[(long long)b * ldx + a];
+    const int p = spos[b]; // (a row-sharded basis side keeps the rows [row0, row1) of Binv0 only)
+    if (p >= row0 && p < row1) binv[(long long)p * ldb + a] = X[(long long)b * ldx + a];
 }
 
 // As[i][b] = A[lrow[i], column of the b-th structural basic]   grid (ceil(k/256), nl)
@@ -1132,7 +1158,7 @@ double *dzg_launch_refactor_b(const DzgDev &d, int k, int nl, double *G, double 
         }
         // ---- Binv0 rows of the structural positions
         hipLaunchKernelGGL(k_ref_scatter, dim3((k + 255) / 256, k), dim3(256), 0, st, k, Xf, ldg, spos,
-                           d.binv, d.ldb);
+                           d.binv, d.ldb, d.rs ? d.rs_r0 : 0, d.rs ? d.rs_r1 : d.m);
         // ---- Binv0 rows of the basic slacks: -A[r', S] * X   (A[r', S] goes into the free panel)
         if (nl > 0) {
             int own0, own1;
@@ -1161,12 +1187,15 @@ void dzg_launch_refactor_c(const DzgDev &d, int k, int nl, double *G, double *X,
     if (k > 0 && nl > 0 && !d.spb) {
         const double *Xf = G; // the finished inverse (stage B)
         double *Wk = X;       // A[L, S]
+        // (lpos ascends: a row-sharded rank's rows are a contiguous run of the list, the workgroups
+        // outside it return at once)
+        const int row0 = d.rs ? d.rs_r0 : 0, row1 = d.rs ? d.rs_r1 : 0;
         if (!std::getenv("DZG_REF_GEMM_STRIPS"))
             hipLaunchKernelGGL((k_ref_gemm_lds<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
-                               nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
+                               nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos, row0, row1);
         else
             hipLaunchKernelGGL((k_ref_gemm<true>), dim3((k + 63) / 64, (nl + 63) / 64), dim3(256), 0, st,
-                               nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos);
+                               nl, k, k, Wk, ldg, Xf, ldg, d.binv, d.ldb, (const int *)lpos, row0, row1);
     }
     hipLaunchKernelGGL(k_ref_done, dim3(1), dim3(1), 0, st, d.ctl, singular);
 }

@@ -629,7 +629,8 @@ __device__ __forceinline__ int sp_pivot_books(
         if (c.first_near_tie < 0) ctl->first_near_tie = it;
     }
     if (c.tie_tol >= 0.0) {
-        const double adaptive = 64.0 * max_err;
+        double adaptive = 64.0 * max_err;
+        if (c.drift_tau > adaptive) adaptive = c.drift_tau;
         ctl->tau = adaptive > c.tie_tol ? adaptive : c.tie_tol;
     }
     ctl->iter = it + 1;

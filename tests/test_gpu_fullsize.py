@@ -326,6 +326,36 @@ def test_config5_column_sharded_over_8_ranks_partitioned(core, config5):
         assert res.max_pivot_error == single.max_pivot_error
 
 
+def test_config5_row_sharded_over_8_ranks_from_a_warm_start(core, config5):
+    """config 5 DEEP in its solve -- warm-started from a basis of 16 384 structural
+    columns (core.warm_started; the compact inverse is 32768 x 16384, 4.3 GB) -- column-block
+    PARTITIONED over 8 ranks with the basis side sharded by rows (opts.shard_rows: a rank keeps 4096
+    rows of the inverse, 0.54 GB).  The ranks factorise the starting basis together (their shares of
+    A[R, S] and A[L, S] summed over the ranks) and then take, bit for bit, the single-GPU solver's
+    pivots from the same state: mu of every pivot, x, xbar, basis, objective, monitor."""
+    from dantzig_amd.sharded import make_lockstep, run_lockstep
+
+    a, b, c = config5
+    lp = core.warm_started(core.CoreLP.from_inequality_form(a, b, c), 16384)
+    single = core.solve(lp, numerics=core.FAST, max_iter=48, poll_interval=16)
+    assert single.status == "iter_limit" and single.refactors == 1 and single.dense_columns > 16300
+    assert single.max_pivot_error < 1e-8
+    solvers = make_lockstep(lp, 8, replicate=False, shard_rows=True, max_iter=48, poll_interval=16)
+    try:
+        status = run_lockstep(solvers)
+        results = [s.result() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    assert status == "iter_limit"
+    for res in results:
+        assert res.refactors == 1
+        assert res.pivots == single.pivots           # kind, entering, leaving AND mu, exactly
+        assert np.array_equal(res.x, single.x) and np.array_equal(res.xbar, single.xbar)
+        assert np.array_equal(res.basis, single.basis) and res.objective == single.objective
+        assert res.max_pivot_error == single.max_pivot_error and res.min_margin == single.min_margin
+
+
 def test_config5_pricing_pass_properties(core, config5):
     """The streaming kernel at 32768 rows (256 tiles per column): against float64 numpy on
     sampled columns, linear in v, independent of which other columns are priced with it."""

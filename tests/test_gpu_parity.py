@@ -882,6 +882,35 @@ def test_near_tie_stop_is_resumable(core):
     assert len(r2.margins) == len(r2.pivots) and r2.min_margin <= r2.margins.min()
 
 
+def test_state_drift_is_measured_at_a_refactorisation(core):
+    """the near-tie tolerance followed the INVERSE's consistency only (64 x
+    max_pivot_error, which a fresh inverse resets), while the carried x, xbar, z keep the rounding of
+    every pivot so far.  At a refactorisation they are now recomputed from the fresh inverse
+    (csrc/k_drift.hip: B^-1 b, B^-1 xbar0, N^T B^-T c_B - c_N), the largest relative difference is
+    reported as state_drift and tau = max(tie_tol, 64 max_pivot_error, 4 state_drift).  512 x 1024
+    against the oracle's 7 692 pivots with a refactorisation every 2 000: the pivots are the
+    oracle's (COUNT mode: a flag changes no decision), the drift is measured, tiny and not zero,
+    and every pivot after the last refactorisation whose margin lies inside 4 x drift is booked."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_pivots_2001_512x1024.npz"))
+    a, b, c = core.gen_dense_lp(seed=int(fx["seed"]), m=int(fx["m"]), n_struct=int(fx["n_struct"]))
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    plain = core.solve(lp, numerics=core.FAST, poll_interval=50)
+    assert plain.state_drift == 0.0 and plain.refactors == 0          # (never measured: no refactorisation)
+    r = core.solve(lp, numerics=core.FAST, poll_interval=50, refactor_interval=2000)
+    assert r.status == "optimal" and r.iterations == int(fx["iterations"]) and r.refactors == 3
+    assert np.array_equal(np.array([p[1] for p in r.pivots]), fx["entering"])
+    assert np.array_equal(np.array([p[2] for p in r.pivots]), fx["leaving"])
+    assert 0.0 < r.state_drift < 1e-7, r.state_drift
+    tau = max(1e-11, 4.0 * r.state_drift)
+    late = r.margins[6000:]                                             # (after the last refactorisation)
+    assert r.near_ties >= int((late <= tau).sum())
+    # the oracle's mu against FAST's: the drift the tolerance now knows about is of that order
+    mu_gap = max(abs(p[3] - w) / max(1.0, abs(w)) for p, w in zip(r.pivots, fx["mu"]))
+    assert mu_gap < 1e-6
+    print(f"state_drift {r.state_drift:.3e}, near_ties {r.near_ties}, first {r.first_near_tie}, "
+          f"FAST-vs-oracle mu gap {mu_gap:.3e}, min margin {r.min_margin:.3e}")
+
+
 def test_continuous_lp_is_not_flagged(core):
     """BASELINE config 2's family at 512 x 1024: thousands of pivots on continuous data, the
     oracle's log taken pivot for pivot, no near tie met -- AUTO keeps FAST's answer."""
