@@ -373,10 +373,16 @@ def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
         if rc.kernel_launches["ratio"] > rb.kernel_launches["ratio"] and \
                 rc.kernel_launches["status"] == rb.kernel_launches["status"]:
             # the sparse-basis path (csrc/k_sparse.hip): status() is the head of the FTRAN launch
-            names = {"ftran": "status + primal FTRAN (k_sp_ftran_s<0>, k_sp_ftran_l)",
-                     "btran": "BTRAN row", "price": "pricing",
-                     "ratio": "dual ratio test + FTRAN (k_sp_ftran_s<1>, k_sp_ftran_l)",
-                     "update": "pivot + update", "basis_update": "eta flush (amortised)"}
+            if rc.kernel_launches["btran"] > rb.kernel_launches["btran"]:  # eight launches (DZG_SP_FUSED=0)
+                names = {"ftran": "status + primal FTRAN (k_sp_ftran_s<0>, k_sp_ftran_l)",
+                         "btran": "BTRAN row", "price": "pricing",
+                         "ratio": "dual ratio test + FTRAN (k_sp_ftran_s<1>, k_sp_ftran_l)",
+                         "update": "pivot + update", "basis_update": "eta flush (amortised)"}
+            else:  # four launches
+                names = {"ftran": "k_sp_pre: status, primal FTRAN (both halves) + ratio test, BTRAN row",
+                         "price": "pricing (k_price_csc_rl)",
+                         "ratio": "k_sp_mid: dual ratio test + FTRAN (both halves), the pivot's books",
+                         "update": "k_sp_update", "basis_update": "eta flush (amortised)"}
         elif rc.kernel_launches["status"] > rb.kernel_launches["status"]:
             names = {"status": "status + primal FTRAN prep", "ftran": "FTRAN GEMV (primal)",
                      "btran": "BTRAN row", "price": "pricing",
@@ -526,7 +532,8 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
                          f"nonzeros per column (CSC), generator G2 seed {seed}"),
             "numerics": r1.numerics,
             "price_kernel": price_name,
-            "launches_per_iteration": (8 if sparse_per_col > 0 else 7 if SEVEN_LAUNCHES else
+            "launches_per_iteration": ((8 if os.environ.get("DZG_SP_FUSED") == "0" else 4)
+                                       if sparse_per_col > 0 else 7 if SEVEN_LAUNCHES else
                                        4 if (rows_on and r1.dense_columns < rows_T) else 3)
             if numerics_name == "fast" else None,
             "status_after_timed_region": status,

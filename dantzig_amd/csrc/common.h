@@ -404,6 +404,11 @@ struct DzgDev {
     // and U; rs == 0: all of them (rs_r0 = 0, rs_r1 = m)
     int rs, rs_r0, rs_r1;
     long long rs_mcol;   // doubles of a record's column section (0: the matrix is replicated)
+    int ftran_variant;   // how FTRAN loads the rows of Binv0 (fast_gemv_row_head<.., VAR>): >= 0 forced
+                         // (DZG_FTRAN_VARIANT), -1: nontemporal from k = ftran_nt_k on, plain below
+    int ftran_nt_k;      // 8 m k bytes of inverse beyond 1.5 x the 256-MB Infinity Cache
+    int fold_k;          // k_chain_post finishes the row-wise pricing pass itself while k stays below
+                         // this (few row groups: few partial sums per column); DZG_CHAIN_FOLD_K
 };
 
 #ifdef __HIPCC__
@@ -433,7 +438,9 @@ int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *
 
 // k_price.hip
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
-void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind = -1);
+void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind = -1,
+                           int skip_finish = 0);
+int dzg_price_rows_certain(const DzgDev &d, int kernel); // the host's bounds on k prove the row-wise pass
 void dzg_launch_transpose_to_rows(const double *A, long long lda, int m, int n, double *At,
                                   long long ldt, hipStream_t st);
 int dzg_price_rows_groups(void);
@@ -487,7 +494,7 @@ void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
                           unsigned long long *dbg, const double *xrecv, hipStream_t st);
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
                            unsigned long long *dbg, int only_partials, int nrz, const double *xrecv,
-                           hipStream_t st);
+                           hipStream_t st, int fold = 0);
 
 // k_rowshard.hip: column sharding with the basis side sharded by rows too (opts.shard_rows)
 void dzg_launch_rs_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);
@@ -514,3 +521,8 @@ void dzg_launch_sp_pivot(const DzgDev &d, hipStream_t st);
 void dzg_launch_sp_update(const DzgDev &d, int only_partials, hipStream_t st);
 void dzg_launch_sp_flush(const DzgDev &d, hipStream_t st);
 void dzg_launch_sp_ref_copy(const DzgDev &d, int k, const double *Xinv, long long ldx, hipStream_t st);
+// the same iteration in four launches (k_sp_pre, pricing, k_sp_mid, k_sp_update)
+int dzg_sp_grid(int m);
+int dzg_sp_fused_resident_per_cu(void);
+void dzg_launch_sp_pre(const DzgDev &d, unsigned long long *bar, hipStream_t st);
+void dzg_launch_sp_mid(const DzgDev &d, unsigned long long *bar, int nrz, hipStream_t st);

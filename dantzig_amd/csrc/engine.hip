@@ -129,6 +129,8 @@ struct dzg_solver {
     long long chain_kcap = DZG_CHAIN_AGCAP;  // compact width beyond which a batch runs as seven
                                              // launches (DZG_CHAIN_KCAP lowers it: tests)
     bool batch_chain = false;                // the batch in flight runs the chain
+    bool chain_fold = true;                  // k_chain_post finishes the row-wise pricing pass itself
+                                             // (DZG_CHAIN_NO_FOLD=1 at creation: the separate launch)
     int64_t chain_fallbacks = 0;             // barrier failures recovered from (chain_recover)
     long long chain_retry_iter = 0;          // the chain stays off until this pivot count
     // column sharding
@@ -375,6 +377,17 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     d.lda = ((long long)m + 15) / 16 * 16 + (m >= 2048 ? 272 : 0);
     if (d.lda == 0) d.lda = 16;
     d.eps = o.epsilon;
+    // FTRAN's loads of Binv0's rows (k > 512): nontemporal, eight steps in flight -- 125.4 -> 102.9 us
+    // for k_chain_pre at k = 7 700 (profiles/r04_ftran_row_loads_ab.txt); DZG_FTRAN_VARIANT=0: plain loads
+    d.ftran_variant = -1;
+    if (const char *fv = std::getenv("DZG_FTRAN_VARIANT")) d.ftran_variant = std::atoi(fv);
+    {
+        const double kk = 384e6 / (8.0 * (double)(lp->m > 0 ? lp->m : 1));
+        d.ftran_nt_k = kk > 2e9 ? 2000000000 : (int)kk;
+        if (d.ftran_nt_k < 513) d.ftran_nt_k = 513;
+    }
+    d.fold_k = 256;
+    if (const char *fk = std::getenv("DZG_CHAIN_FOLD_K")) d.fold_k = std::atoi(fk);
     d.world = o.world > 1 ? o.world : 1;
     d.rank = d.world > 1 ? o.rank : 0;
     d.col0 = 0;
@@ -652,6 +665,18 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.fpx_h, np)); TRY(dev_alloc(s, &d.fpz_h, np));
         TRY(dev_alloc(s, &d.rx_h, np)); TRY(dev_alloc(s, &d.rz_h, np));
         if (o.refactor_interval != 0) TRY(refactor_workspace(s));
+        if (d.spb && !o.seven_launches) {
+            // the four-launch iteration (k_sp_pre / k_sp_mid, k_sparse.hip) synchronises its phases with
+            // device-wide barriers: every workgroup of its grid must be resident at once
+            hipDeviceProp_t prop;
+            HIP_OK(hipGetDeviceProperties(&prop, o.device));
+            const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+            const char *off = std::getenv("DZG_SP_FUSED");
+            if (!(off && off[0] == '0') && (long long)dzg_sp_fused_resident_per_cu() * cus >= dzg_sp_grid(m)) {
+                TRY(dev_alloc(s, &s->chain_bar, (size_t)DZG_CHAIN_BAR_WORDS));
+                HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * DZG_CHAIN_BAR_WORDS, s->st));
+            }
+        }
         if (d.spb) {
             TRY(dev_alloc(s, &d.sslot, (size_t)m)); TRY(dev_alloc(s, &d.spos, (size_t)m));
             TRY(dev_alloc(s, &d.bslot, (size_t)(ns ? ns : 1))); TRY(dev_alloc(s, &d.rowpos, (size_t)m));
@@ -690,6 +715,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
                         HIP_OK(hipMemsetAsync(s->chain_dbg, 0, sizeof(unsigned long long) * 64, s->st));
                     }
                 }
+                if (const char *nf = std::getenv("DZG_CHAIN_NO_FOLD")) s->chain_fold = nf[0] != '1';
                 TRY(dev_alloc(s, &s->chain_bar, (size_t)DZG_CHAIN_BAR_WORDS));
                 HIP_OK(hipMemsetAsync(s->chain_bar, 0, sizeof(unsigned long long) * DZG_CHAIN_BAR_WORDS, s->st));
             }
@@ -839,11 +865,14 @@ static void enqueue_chain_iteration(dzg_solver *s, int slot)
     pf.begin(DZG_K_FTRAN);
     dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, nullptr, st); // status, primal FTRAN + ratio, BTRAN row
     pf.end(DZG_K_FTRAN);
+    // while the batch prices row-wise for certain, k_chain_post finishes the pass itself (FOLD)
+    const int fold = s->chain_fold && dzg_price_rows_certain(d, pk);
     pf.begin(DZG_K_PRICE);
-    dzg_launch_price_fast(d, pk, st);
+    dzg_launch_price_fast(d, pk, st, -1, fold);
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_UPDATE);
-    dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0, price_partials_for(s, pk), nullptr, st);
+    dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0,
+                          fold ? s->chain_grid : price_partials_for(s, pk), nullptr, st, fold);
     pf.end(DZG_K_UPDATE);
     pf.begin(DZG_K_BASIS_UPDATE);
     if (++s->since_flush >= DZG_RMAX) {
@@ -859,6 +888,28 @@ static void enqueue_sparse_iteration(dzg_solver *s, int slot)
     const DzgDev &d = s->d;
     hipStream_t st = s->st;
     Prof pf{s, slot};
+    if (s->batch_chain) { // four launches: the phases of one side of the pricing pass share a launch
+        const int pk = price_kernel_for(s);
+        pf.begin(DZG_K_FTRAN);
+        dzg_launch_sp_pre(d, s->chain_bar, st); // status, primal FTRAN (both halves) + ratio test, BTRAN row
+        pf.end(DZG_K_FTRAN);
+        pf.begin(DZG_K_PRICE);
+        dzg_launch_price_fast(d, pk, st);
+        pf.end(DZG_K_PRICE);
+        pf.begin(DZG_K_RATIO);
+        dzg_launch_sp_mid(d, s->chain_bar, price_partials_for(s, pk), st); // dual ratio + FTRAN; the books
+        pf.end(DZG_K_RATIO);
+        pf.begin(DZG_K_UPDATE);
+        dzg_launch_sp_update(d, 0, st);
+        pf.end(DZG_K_UPDATE);
+        pf.begin(DZG_K_BASIS_UPDATE);
+        if (++s->since_flush >= DZG_RMAX) {
+            dzg_launch_sp_flush(d, st);
+            s->since_flush = 0;
+        }
+        pf.end(DZG_K_BASIS_UPDATE);
+        return;
+    }
     pf.begin(DZG_K_FTRAN);
     dzg_launch_sp_ftran(d, DZG_STEP_PRIMAL, 0, st); // status() + primal FTRAN (a no-op in a dual step)
     pf.end(DZG_K_FTRAN);
@@ -892,7 +943,7 @@ static void collect_profile(dzg_solver *s, int slots_real)
             if (s->d.csc && !s->d.spb && s->d.world == 1 && !s->comm && cls != DZG_K_PRICE)
                 continue; // the single-GPU record path of a CSC solver only stamps pricing
             if (s->batch_chain && s->d.world == 1 && !s->comm &&
-                (cls == DZG_K_STATUS || cls == DZG_K_BTRAN || cls == DZG_K_RATIO))
+                (cls == DZG_K_STATUS || cls == DZG_K_BTRAN || (cls == DZG_K_RATIO && !s->d.spb)))
                 continue; // the chain has no launches of their own for these
             float ms = 0.f;
             size_t base = ((size_t)slot * DZG_K_COUNT + cls) * 2;
@@ -1259,6 +1310,7 @@ static int run_fast(dzg_solver *s)
         const int k_low = (int)s->h_ctl->ncompact > batch ? (int)s->h_ctl->ncompact - batch : 0;
         if (s->d.spb) {
             s->d.k_hint = k_bound;
+            s->batch_chain = s->chain_bar && s->h_ctl->iter >= s->chain_retry_iter;
             for (int b = 0; b < batch; ++b) enqueue_sparse_iteration(s, b);
             s->d.k_hint = 0;
         } else if (s->d.csc) { // sparse input: the record-based phases, exchanging with itself
@@ -1498,6 +1550,10 @@ extern "C" int dzg_shard_phase3(dzg_solver *s, const double *recv_dev)
     phase_stamp(s, DZG_K_UPDATE, 0);
     if (d.rs) {
         if (!s->rs_recv1) return fail(DZG_E_ARG, "phase3 before phase2");
+        if (s->rs_recv1 == recv_dev)
+            return fail(DZG_E_ARG, "shard_rows: phase 3 still reads the records of exchange 1 (the leaving "
+                                   "row of a dual step, the entering column of a primal one): the second "
+                                   "exchange needs a receive buffer of its own");
         dzg_launch_rs_select(d, 1, recv_dev, st);                          // merge (+ prep / v)
         dzg_launch_price_fast(d, price_kernel_for(s), st, DZG_STEP_PRIMAL); // primal: pricing
         dzg_launch_rs_gemv(d, DZG_STEP_DUAL, s->rs_recv1, recv_dev, st);   // dual: FTRAN + dx_p

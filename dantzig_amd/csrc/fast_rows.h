@@ -75,7 +75,10 @@ __device__ __forceinline__ double fast_beta_dot(const double *__restrict__ wt,
 // compact row of Binv0 against the gathered column `ag` (padded with a zero to an even length);
 // (tail) minus this lane's share of the eta file, then the sum over the LPR lanes.  The summation
 // order depends on LPR, k and neta only.  Rows i >= m: zero (the lanes still take part in the tail).
-template <int LPR>
+// VAR (the loads of the row only; the sums and their order are the same in every variant):
+//   0  plain loads, four steps' loads in flight          1  nontemporal loads
+//   2  nontemporal loads, eight steps' loads in flight
+template <int LPR, int VAR = 0>
 __device__ __forceinline__ double fast_gemv_row_head(int i, int m, int k2,
                                                      const double *__restrict__ binv, long long ldb,
                                                      const double *__restrict__ ag, int sub)
@@ -84,6 +87,27 @@ __device__ __forceinline__ double fast_gemv_row_head(int i, int m, int k2,
     const double *row = binv + (long long)i * ldb;
     double a0 = 0.0, a1 = 0.0;
     int c = 2 * sub;
+    if (VAR != 0) {
+        constexpr int UN = VAR == 2 ? 8 : 4;
+#pragma unroll UN
+        for (; c + 2 * LPR < k2; c += 4 * LPR) {
+            const double2_t r0 = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(row + c));
+            const double2_t r1 = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(row + c + 2 * LPR));
+            const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+            const double2_t g1 = *reinterpret_cast<const double2_t *>(ag + c + 2 * LPR);
+            a0 = fma(r0.x, g0.x, a0);
+            a1 = fma(r1.x, g1.x, a1);
+            a0 = fma(r0.y, g0.y, a0);
+            a1 = fma(r1.y, g1.y, a1);
+        }
+        for (; c < k2; c += 2 * LPR) {
+            const double2_t r0 = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(row + c));
+            const double2_t g0 = *reinterpret_cast<const double2_t *>(ag + c);
+            a0 = fma(r0.x, g0.x, a0);
+            a0 = fma(r0.y, g0.y, a0);
+        }
+        return a0 + a1;
+    }
     // (unrolled: the loads of four steps leave together -- a wide inverse streams from HBM and one
     // wave per row keeps too few bytes in flight otherwise -- the sums are taken in the same order)
 #pragma unroll 4
@@ -118,14 +142,14 @@ __device__ __forceinline__ double fast_gemv_row_tail(double acc, int i, int m, i
     return acc;
 }
 
-template <int LPR>
+template <int LPR, int VAR = 0>
 __device__ __forceinline__ double fast_gemv_row(int i, int m, int k2, int neta,
                                                 const double *__restrict__ binv, long long ldb,
                                                 const double *__restrict__ ag,
                                                 const double *__restrict__ U, long long ldu,
                                                 const double *__restrict__ beta, int sub)
 {
-    const double acc = fast_gemv_row_head<LPR>(i, m, k2, binv, ldb, ag, sub);
+    const double acc = fast_gemv_row_head<LPR, VAR>(i, m, k2, binv, ldb, ag, sub);
     return fast_gemv_row_tail<LPR>(acc, i, m, neta, U, ldu, beta, sub);
 }
 

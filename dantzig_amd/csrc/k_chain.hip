@@ -212,6 +212,27 @@ __device__ __forceinline__ void chain_dot_head(const DzgDev &d, int r0, int r1, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR, grp = lane / LPR;
     const int k2 = (k + 1) & ~1;
+    // (block-uniform) how the rows are loaded: an inverse that outgrows the 256-MB Infinity Cache
+    // streams past the caches (nontemporal loads, eight steps in flight: 125.4 -> 102.9 us per FTRAN
+    // at k = 7 700 of config 3), a smaller one is re-read from it pivot after pivot and plain loads
+    // are faster (55.4 against 60.4 us at k = 4 049): profiles/r04_ftran_row_loads_ab.txt
+    const int variant = d.ftran_variant >= 0 ? d.ftran_variant : (k >= d.ftran_nt_k ? 2 : 0);
+    if (LPR == 64 && variant == 1) {
+#pragma unroll
+        for (int pass = 0; pass < CH_MAXP; ++pass) {
+            const int i = r0 + (pass * CH_NW + wave) * RPW + grp;
+            accs[pass] = fast_gemv_row_head<LPR, 1>(i < r1 ? i : d.m, d.m, k2, d.binv, d.ldb, s_ag, sub);
+        }
+        return;
+    }
+    if (LPR == 64 && variant == 2) {
+#pragma unroll
+        for (int pass = 0; pass < CH_MAXP; ++pass) {
+            const int i = r0 + (pass * CH_NW + wave) * RPW + grp;
+            accs[pass] = fast_gemv_row_head<LPR, 2>(i < r1 ? i : d.m, d.m, k2, d.binv, d.ldb, s_ag, sub);
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < CH_MAXP; ++pass) {
         const int i = r0 + (pass * CH_NW + wave) * RPW + grp;
@@ -421,6 +442,29 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
     ts.done(slot);
 }
 
+// dz of ONE nonbasic position as the finishing launch of the row-wise pricing pass computes it
+// (k_price_rows_finish, k_price_kernels.h): the G partial sums of the row groups in group order for
+// a structural column, the unit column's single product otherwise.
+__device__ __forceinline__ double chain_fold_dz(const DzgDev &d, int code, int G)
+{
+    if (code < 0) {
+        const double p = 1.0 * -d.v[-1 - code];
+        return 0.0 + p; // Iterator::sum identity + the single stored entry
+    }
+    const double *src = d.ppart + (code - d.col0);
+    double sum = 0.0;
+    int gg = 0;
+    for (; gg + 8 <= G; gg += 8) { // eight partials side by side, added in group order
+        double t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = src[(long long)(gg + e) * d.ldt];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum = sum + t[e];
+    }
+    for (; gg < G; ++gg) sum = sum + src[(long long)gg * d.ldt];
+    return -sum;
+}
+
 // ---------------------------------------------------------------------------------
 // k_chain_post: a dual step's ratio test and FTRAN (src/simplex.rs:324-325, :226-229), the pivot's
 // books (fast_rows.h; the last wave of workgroup 0, beside everybody's update), pivot() x4
@@ -430,11 +474,17 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_pre(const DzgDev d, unsign
 // SHARD: the ratio test of a dual step is the merge of the ranks' proposals (xrecv: the second
 // exchange's records), z, zbar, dz of the entering position come from its owner's record, and z is
 // only kept -- and offered as a first-pivot candidate -- for slack positions and owned columns.
+// FOLD (one GPU, the row-wise pricing pass, round 4): the pass's FINISHING launch is this kernel's
+// head -- a workgroup owns its columns of z anyway: thread t adds the row groups' partial sums of
+// position q0 + t itself (the finishing launch's arithmetic, chain_fold_dz), a dual step's ratio
+// candidates are reduced per workgroup and cross one more device-wide barrier (a primal step needs
+// none), and dz_r of the entering position is re-derived by every workgroup.  One launch and its
+// cold first touches less per pivot; the same sums and candidates, bit for bit.
 template <bool SHARD>
 __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsigned long long *bar,
                                                            const DzgPivotArgs pa, int only_partials,
                                                            int nrz, unsigned long long *dbg,
-                                                           const double *__restrict__ xrecv)
+                                                           const double *__restrict__ xrecv, int fold)
 {
     __shared__ double s_ag[CH_AGCAP];
     __shared__ double s_beta[R_], s_dx[CH_THREADS];
@@ -451,8 +501,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
     DzgCand2 mine = dzg_cand2_none();
     ChainSpec sp;
     const bool one_wave = nrz <= 256; // (block-uniform) the candidates fit one wave's registers
-    if (SHARD) {
-        // (the candidates travel in the exchange records)
+    if (SHARD || fold) {
+        // (the candidates travel in the exchange records / are formed below)
     } else if (!only_partials && one_wave) {
         if (wave == 0) chain_spec_load(sp, d.rz_r, d.rz_k, d.rz_h, lane);
     } else if (!only_partials) {
@@ -492,8 +542,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
     if (has_col) {
         z_k = d.z[col];
         zbar_k = d.zbar[col];
-        if (!only_partials) dz_k = d.dz[col];
-        if (SHARD) nbcode_k = d.nbcode[col]; // (before the books of this launch rewrite position r's)
+        if (!only_partials && !fold) dz_k = d.dz[col];
+        if (SHARD || fold) nbcode_k = d.nbcode[col]; // (before the books of this launch rewrite position r's)
     }
     DzgCtl c = *ctl;
     if (c.status != DZG_RUNNING) return;
@@ -508,6 +558,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
         p = c.leave_pos;
         int cj, edslot;
         double zr, zbr, dzr, dxp;
+        int G = (k + 1 + DZG_PR_BATCH - 1) / DZG_PR_BATCH; // row groups of the pricing pass (FOLD)
+        G = G > DZG_PR_GMAX ? DZG_PR_GMAX : G;
+        if (!SHARD && fold && has_col) dz_k = chain_fold_dz(d, nbcode_k, G);
         if (kind == DZG_STEP_DUAL) {
             const int dr0 = tid < k ? d.drow[tid] : -1;
             const int dr1 = tid + CH_THREADS < k ? d.drow[tid + CH_THREADS] : -1;
@@ -515,6 +568,40 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             int w_rec = -1;
             if (SHARD) {
                 w_rec = shard_merge(xrecv, d.xstride, d.world, cw);
+            } else if (fold) {
+                // the ratio test of the z side (src/simplex.rs:449-460) on this workgroup's columns;
+                // the workgroups' winners cross a barrier, everybody reduces them
+                DzgCand2 cnd = dzg_cand2_none();
+                if (has_col) {
+                    const double scaled = c.mu * zbar_k, den = z_k + scaled;
+                    DzgCand2 o;
+                    o.r = dzg_div(dz_k, den);
+                    o.k = col;
+                    o.h = -__builtin_inf();
+                    if (o.r > 0.0) cnd = dzg_better2(cnd, o);
+                    if (dzg_noise_zero(den, z_k, scaled, c.tau)) cnd.h = __builtin_inf();
+                }
+                cnd = chain_best(cnd, q1 - q0);
+                if (tid == 0) {
+                    st_sc1(d.rz_r + blockIdx.x, cnd.r);
+                    st_sc1(d.rz_k + blockIdx.x, cnd.k);
+                    st_sc1(d.rz_h + blockIdx.x, cnd.h);
+                }
+                if (!chain_barrier(ctl, bar, gen)) return;
+                if (wave == 0) {
+                    DzgCand2 w = dzg_cand2_none();
+                    for (int i = lane; i < (int)gridDim.x; i += 64) {
+                        DzgCand2 o;
+                        o.r = ld_sc1(d.rz_r + i);
+                        o.k = ld_sc1(d.rz_k + i);
+                        o.h = ld_sc1(d.rz_h + i);
+                        w = dzg_better2(w, o);
+                    }
+                    w = dzg_wave_best2(w);
+                    if (lane == 0) chain_put(s_c, 0, w);
+                }
+                __syncthreads();
+                cw = chain_get(s_c, 0);
             } else if (one_wave) {
                 if (wave == 0) {
                     const DzgCand2 w = chain_spec_reduce(sp, nrz, lane);
@@ -525,7 +612,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             } else {
                 cw = dzg_block_best2(mine);
             }
-            if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_INFEASIBLE)) return; // :325
+            if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_INFEASIBLE)) { // :325
+                if (lead && gen != c.bar_gen) ctl->bar_gen = gen;
+                return;
+            }
             slot = 3;
             ts.mark(slot); // 0: first touches + ratio test
             r = cw.k;
@@ -546,7 +636,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
                 cj = d.nbcode[r];
                 zr = d.z[r];
                 zbr = d.zbar[r];
-                dzr = d.dz[r];
+                dzr = fold ? chain_fold_dz(d, cj, G) : d.dz[r];
             }
             const double *a = chain_col<SHARD>(d, cj, xrecv, w_rec);
             edslot = cj < 0 ? d.dslot[-1 - cj] : -1;
@@ -608,7 +698,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             cj = c.enter_code;
             zr = c.zr;
             zbr = c.zbar_r;
-            dzr = d.dz[r];
+            dzr = (!SHARD && fold) ? chain_fold_dz(d, cj, G) : d.dz[r];
             if (SHARD) { // the owner of the entering position has published z, zbar, dz
                 int w_rec = -1;
                 for (int rk = 0; rk < d.world && w_rec < 0; ++rk)
@@ -765,14 +855,14 @@ void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
 
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
                            unsigned long long *dbg, int only_partials, int nrz, const double *xrecv,
-                           hipStream_t st)
+                           hipStream_t st, int fold)
 {
     if (xrecv)
         hipLaunchKernelGGL(k_chain_post<true>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar,
-                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv);
+                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv, 0);
     else
         hipLaunchKernelGGL(k_chain_post<false>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar,
-                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv);
+                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv, fold);
 }
 
 // ---------------------------------------------------------------------------------

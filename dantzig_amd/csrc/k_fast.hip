@@ -182,7 +182,7 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
                                           const double *__restrict__ x,
                                           const double *__restrict__ xbar,
                                           double *__restrict__ dx, DzgCand2 &best, int want_row,
-                                          double *want_dx)
+                                          double *want_dx, bool nt)
 {
     constexpr int RPW = 64 / LPR; // rows per wave and pass
     const int lane = threadIdx.x & 63;
@@ -193,7 +193,11 @@ __device__ __forceinline__ void gemv_rows(const DzgCtl *ctl, int need_kind, int 
     const double mu = ctl->mu, tau = ctl->tau;
     for (int i0 = wave_global * RPW; i0 < m; i0 += nwaves * RPW) {
         const int i = i0 + grp;
-        double acc = fast_gemv_row<LPR>(i, m, k2, neta, binv, ldb, ag, U, ldu, beta, sub);
+        // (one wave per row of a wide inverse: the row streams past the caches, eight steps' loads in
+        // flight -- profiles/r04_ftran_row_loads_ab.txt; the sums are the same sums)
+        double acc = (LPR == 64 && nt)
+                         ? fast_gemv_row<LPR, 2>(i, m, k2, neta, binv, ldb, ag, U, ldu, beta, sub)
+                         : fast_gemv_row<LPR, 0>(i, m, k2, neta, binv, ldb, ag, U, ldu, beta, sub);
         if (i < m && sub == 0) {
             acc = fast_gemv_unit(acc, bcode[i], code, acolp);
             dx[i] = acc;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
     const double *__restrict__ xrecv, long long xstride, const int *__restrict__ bcode,
     const double *__restrict__ x, const double *__restrict__ xbar, double *__restrict__ dx,
     double *__restrict__ rx_r, int *__restrict__ rx_k, double *__restrict__ rx_h,
-    DzgPivotArgs pa)
+    DzgPivotArgs pa, int nt_k)
 {
     const DzgCtl c = *ctl; // one snapshot of the control block (scalar loads)
     if (c.status != DZG_RUNNING) return;
@@ -244,10 +248,10 @@ __global__ __launch_bounds__(256) void k_fast_gemv(
     const bool owner = PIVOT && ((p / rpw) % nwaves) / (int)(blockDim.x >> 6) == (int)blockIdx.x;
     if (k > 512)
         gemv_rows<64>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, bcode,
-                      x, xbar, dx, best, p, &s_dxp);
+                      x, xbar, dx, best, p, &s_dxp, k >= nt_k);
     else
         gemv_rows<16>(&c, need_kind, m, k, neta, code, binv, ldb, ag, U, ldu, beta, acolp, bcode,
-                      x, xbar, dx, best, p, &s_dxp);
+                      x, xbar, dx, best, p, &s_dxp, false);
     if (need_kind == DZG_STEP_PRIMAL) {
         best = dzg_block_best2(best);
         if (threadIdx.x == 0) {
@@ -650,8 +654,28 @@ __global__ __launch_bounds__(256) void k_shard_scatter_col(const DzgCtl *ctl, in
 // ---------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------
+// every partial-candidate array starts as "no candidate, no competition": a launch that has nothing
+// to price (no nonbasic position at all) leaves its array untouched, and the reduction behind it
+// must not read what hipMalloc happened to hand over
+__global__ __launch_bounds__(256) void k_fast_init_partials(double *r, int *k, double *h, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        r[i] = 0.0;
+        k[i] = -1;
+        h[i] = -__builtin_inf();
+    }
+}
+
 void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
 {
+    {
+        const int np = 4096; // (engine.hip allocates 4096 entries per array)
+        double *rs[4] = {d.fpx_r, d.fpz_r, d.rx_r, d.rz_r}, *hs[4] = {d.fpx_h, d.fpz_h, d.rx_h, d.rz_h};
+        int *ks[4] = {d.fpx_k, d.fpz_k, d.rx_k, d.rz_k};
+        for (int a = 0; a < 4; ++a)
+            hipLaunchKernelGGL(k_fast_init_partials, dim3(np / 256), dim3(256), 0, st, rs[a], ks[a], hs[a], np);
+    }
     {
         const int r0 = d.rs ? d.rs_r0 : 0, rows = (d.rs ? d.rs_r1 : d.m) - r0;
         if (rows > 0)
@@ -690,7 +714,8 @@ void dzg_launch_fast_gemv(const DzgDev &d, int need_kind, const double *xrecv, h
 {
     const DzgPivotArgs pa = dzg_pivot_args(d);
 #define GEMV_ARGS d.ctl, need_kind, d.m, d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, d.A, d.lda, d.col0, xrecv,  \
-                  d.xstride, d.bcode, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h, pa
+                  d.xstride, d.bcode, d.x, d.xbar, d.dx, d.rx_r, d.rx_k, d.rx_h, pa,                         \
+                  (d.ftran_variant >= 0 ? (d.ftran_variant ? 0 : 0x7fffffff) : d.ftran_nt_k)
     if (need_kind == DZG_STEP_DUAL)
         hipLaunchKernelGGL((k_fast_gemv<true>), dim3(DZG_NB_GEMV), dim3(256), 0, st, GEMV_ARGS);
     else

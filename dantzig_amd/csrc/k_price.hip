@@ -129,7 +129,18 @@ int dzg_price_rows_groups(void) { return PR_GMAX; }
 // FAST numerics: structural positions from plist, ratio-test partials for the dual step
 // need_kind >= 0 (row-sharded ranks, dense, tree / row-wise kernels only): the pass runs only in an
 // iteration of that step kind
-void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind)
+// 1: the batch being enqueued prices row-wise for certain (dense matrix, row-major copy resident, the
+// host's upper bound on k below the rule's threshold): the chain's last launch may then finish the
+// pass itself (k_chain_post, FOLD) and the finishing launch is left out
+int dzg_price_rows_certain(const DzgDev &d, int kernel)
+{
+    // (... and few row groups: beyond k = fold_k a column's 32 partial sums cost the 96 threads that
+    // own a workgroup's columns more than the finishing launch's 65 536 threads, measured)
+    return !d.csc && d.At && d.q > 0 && resolve(kernel) == DZG_PRICE_TREE && d.k_hint > 0 &&
+           d.k_hint < d.rows_T && d.k_hint < d.fold_k;
+}
+
+void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind, int skip_finish)
 {
     if (d.csc) {
         if (d.spb && d.lcnt && kernel != DZG_PRICE_SEQ) { // sparse basis: the live entries only
@@ -167,9 +178,10 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need
             hipLaunchKernelGGL((k_price_rows<2>), dim3((unsigned)((d.ldt + 511) / 512), PR_GMAX),
                                dim3(256), 0, st, d.ctl, rows_rule, d.At, d.ldt, d.drow, d.bcode, d.vc,
                                d.ppart, need_kind);
-            hipLaunchKernelGGL(k_price_rows_finish, dim3(DZG_PRICE_TREE_BLOCKS), dim3(256), 0, st,
-                               d.ctl, rows_rule, d.ppart, d.ldt, d.q, d.plist, d.pcode, d.nbcode, d.bcode,
-                               d.col0, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, PR_GMAX, need_kind);
+            if (!(skip_finish && !cols_possible))
+                hipLaunchKernelGGL(k_price_rows_finish, dim3(DZG_PRICE_TREE_BLOCKS), dim3(256), 0, st,
+                                   d.ctl, rows_rule, d.ppart, d.ldt, d.q, d.plist, d.pcode, d.nbcode, d.bcode,
+                                   d.col0, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, PR_GMAX, need_kind);
         }
         if (!cols_possible) return;
     }

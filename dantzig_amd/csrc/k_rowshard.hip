@@ -296,10 +296,16 @@ __device__ __forceinline__ void rs_gemv_rows(const DzgDev &d, const DzgCtl &c, i
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int k2 = (k + 1) & ~1;
     const double mu = c.mu, tau = c.tau;
+    const long long own = d.rs_r1 - d.rs_r0;
+    const bool nt = d.ftran_variant >= 0 ? d.ftran_variant != 0 : 8.0 * (double)own * (double)k > 384e6;
     for (int i0 = d.rs_r0 + wave_global * RPW; i0 < d.rs_r1; i0 += nwaves * RPW) {
         const int i = i0 + grp;
         const int ii = i < d.rs_r1 ? i : d.m; // (rows beyond the share: zero, the lanes still fold)
-        double acc = fast_gemv_row<LPR>(ii, d.m, k2, neta, d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, sub);
+        // (a rank's share of the inverse is 8 (m / P) k bytes: it streams past the caches from the
+        // width on at which THAT outgrows the Infinity Cache)
+        double acc = (LPR == 64 && nt)
+                         ? fast_gemv_row<LPR, 2>(ii, d.m, k2, neta, d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, sub)
+                         : fast_gemv_row<LPR, 0>(ii, d.m, k2, neta, d.binv, d.ldb, d.ag, d.U, d.ldw, d.beta, sub);
         if (ii < d.m && sub == 0) {
             acc = fast_gemv_unit(acc, d.bcode[i], code, acolp);
             d.dx[i] = acc;

@@ -31,6 +31,7 @@
 // what this path uses -- is the sparsity of the right-hand sides.
 #include "common.h"
 #include "fast_decide.h"
+#include "chain_barrier.h"
 
 #define R_ DZG_RMAX
 #define SP_NB 1024 // workgroups of the m-sized kernels at most (fixed fan-in of their partials)
@@ -502,9 +503,9 @@ __device__ __forceinline__ int sp_pivot_books(
     int *drow, int *dslot, int *sslot, int *spos, int *bslot, int *rowpos, int *plist, int *pslot,
     const long long *__restrict__ cptr, int *log_kind, int *log_enter, int *log_leave,
     double *log_mu, double *log_margin, long long log_cap, int *bcode, int *nbcode, int *pcode,
-    bool live_lists)
+    bool live_lists, double dxp)
 {
-    const double xp = x[p], xbp = xbar[p], dxp = dx[p];
+    const double xp = x[p], xbp = xbar[p];
     const double zr = z[r], zbr = zbar[r], dzr = dz[r];
     int ok = 1;
     const double t = dzg_safe_divide(xp, dxp, &ok);
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(256) void k_sp_pivot(
         s_ok = sp_pivot_books(ctl, c, m, q, p, r, c.neta, vi, vj, s_ci, s_cj, x, xbar, z, zbar, dx, dz,
                               basis, nonbasis, var_col, drow, dslot, sslot, spos, bslot, rowpos,
                               plist, pslot, cptr, log_kind, log_enter, log_leave, log_mu,
-                              log_margin, log_cap, bcode, nbcode, pcode, lcnt != nullptr);
+                              log_margin, log_cap, bcode, nbcode, pcode, lcnt != nullptr, dx[p]);
     }
     __syncthreads();
     if (!s_ok) return;
@@ -1005,6 +1006,468 @@ __global__ __launch_bounds__(256) void k_sp_ref_copy(int k, const double *__rest
     if (a < k) X[(long long)b * ldb + a] = Xinv[(long long)b * ldx + a];
 }
 
+
+// =================================================================================
+// The same iteration in FOUR launches instead of eight (round 4):
+//
+//      k_sp_pre    status();  a primal step: FTRAN on X's rows | barrier | the basic slacks' rows +
+//                  ratio candidates | barrier | ratio decision;   then BTRAN's row (+ live lists)
+//      pricing     k_price_csc_rl, unchanged
+//      k_sp_mid    a dual step: ratio decision, FTRAN on X's rows | barrier | the basic slacks'
+//                  rows | barrier;   then the pivot's books (workgroup 0)
+//      k_sp_update unchanged (the books' index maps reach it across the kernel boundary)
+//
+// The phases are the bodies of the kernels above, glued with the device-wide barrier of the dense
+// chain (chain_barrier.h: fence-free, fails consistently, every wave reaches its exit).  What
+// crosses a barrier inside a launch -- the dense copy of the entering column (written by workgroup
+// 0), dx on the structural rows of X (`dxs`, gathered by the slack rows), the ratio candidates, and
+// in a dual step dx at the leaving position for the books -- is written with agent-scope (sc1)
+// stores, drained by every storing wave before the workgroup arrives, and read with sc1 loads.
+// Every workgroup takes every decision itself from the same partial results, so no decision
+// crosses a barrier.  Nothing of an iteration's STATE is written before the last barrier of a launch
+// (the live-list append of BTRAN and the books come after it), so a failed barrier leaves the state
+// of the last completed pivot and the host carries on with the eight launches (engine.hip).
+// Same arithmetic in the same order as the eight-launch form: the same pivots, bit for bit.
+// grid = sp_grid(m) workgroups of 256, all resident (checked at creation).
+// =================================================================================
+struct SpStage {
+    int *s_slot;
+    double *s_val;
+    int *s_wcnt;
+};
+
+// the entering column's entries in rows of R, 256 at a time, compacted in their order (see
+// k_sp_ftran_s); returns the count
+__device__ __forceinline__ int sp_stage_chunk(const DzgDev &d, const SpStage &st, int code,
+                                              long long base, long long e1)
+{
+    __syncthreads(); // the previous chunk has been consumed
+    const long long e = base + threadIdx.x;
+    int slot = -1;
+    double val = 0.0;
+    if (e < e1) {
+        const int r = code >= 0 ? d.ridx[e] : -1 - code;
+        slot = d.dslot[r];
+        val = code >= 0 ? d.cval[e] : 1.0;
+    }
+    const unsigned long long mask = __ballot(slot >= 0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) st.s_wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += st.s_wcnt[w];
+    if (slot >= 0) {
+        const int at = off + __popcll(mask & ((1ull << lane) - 1ull));
+        st.s_slot[at] = slot;
+        st.s_val[at] = val;
+    }
+    const int total = st.s_wcnt[0] + st.s_wcnt[1] + st.s_wcnt[2] + st.s_wcnt[3];
+    __syncthreads();
+    return total;
+}
+
+// FTRAN of the entering column `code` (both halves around one barrier).  PRIMAL: also the ratio
+// candidates of this workgroup's rows in `best`.  dx at every position is published with sc1 stores.
+// Returns false when the barrier failed.
+template <int KIND>
+__device__ __forceinline__ bool sp_ftran_fused(const DzgDev &d, DzgCtl *ctl, unsigned long long *bar,
+                                               unsigned long long &gen, int code, int k, int neta,
+                                               double mu, double tau, const SpStage &st,
+                                               double *s_beta, DzgCand2 &best)
+{
+    const long long e0 = code >= 0 ? d.cptr[code] : 0, e1 = code >= 0 ? d.cptr[code + 1] : 1;
+    if (blockIdx.x == 0) { // the dense copy of the entering column, for the basic slacks' rows
+        const int prev = *d.acol_code; // INT_MIN: nothing scattered yet
+        if (prev != (int)0x80000000) {
+            if (prev < 0) {
+                if (threadIdx.x == 0) st_sc1(d.acol + (-1 - prev), 0.0);
+            } else {
+                for (long long e = d.cptr[prev] + threadIdx.x; e < d.cptr[prev + 1]; e += blockDim.x)
+                    st_sc1(d.acol + d.ridx[e], 0.0);
+            }
+        }
+        __syncthreads(); // the two columns may share rows
+        if (code < 0) {
+            if (threadIdx.x == 0) st_sc1(d.acol + (-1 - code), 1.0);
+        } else {
+            for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) st_sc1(d.acol + d.ridx[e], d.cval[e]);
+        }
+        if (threadIdx.x == 0) *d.acol_code = code;
+    }
+    // ---- beta_t = W_t . a_R, thread t (k_sp_ftran_s)
+    double bacc = 0.0;
+    int cnt = 0;
+    for (long long base = e0; base < e1; base += 256) {
+        cnt = sp_stage_chunk(d, st, code, base, e1);
+        if ((int)threadIdx.x < neta) {
+            const double *wt = d.W + (long long)threadIdx.x * d.ldw;
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const double w0 = wt[st.s_slot[i]], w1 = wt[st.s_slot[i + 1]], w2 = wt[st.s_slot[i + 2]],
+                             w3 = wt[st.s_slot[i + 3]];
+                bacc = fma(w0, st.s_val[i], bacc);
+                bacc = fma(w1, st.s_val[i + 1], bacc);
+                bacc = fma(w2, st.s_val[i + 2], bacc);
+                bacc = fma(w3, st.s_val[i + 3], bacc);
+            }
+            for (; i < cnt; ++i) bacc = fma(wt[st.s_slot[i]], st.s_val[i], bacc);
+        }
+    }
+    if (threadIdx.x < R_) s_beta[threadIdx.x] = (int)threadIdx.x < neta ? bacc : 0.0;
+    __syncthreads();
+    // ---- dx on the rows of X
+    const bool one_chunk = e1 - e0 <= 256;
+    for (int b0 = blockIdx.x * blockDim.x; b0 < k; b0 += gridDim.x * blockDim.x) { // block-uniform
+        const int b = b0 + threadIdx.x;
+        const double *row = d.binv + (long long)(b < k ? b : 0) * d.ldb;
+        const int i = b < k ? d.spos[b] : 0;
+        double xi = 0.0, xbi = 0.0;
+        if (KIND == DZG_STEP_PRIMAL && b < k) {
+            xi = d.x[i];
+            xbi = d.xbar[i];
+        }
+        double acc = 0.0;
+        for (long long base = e0; base < e1; base += 256) {
+            if (!one_chunk) cnt = sp_stage_chunk(d, st, code, base, e1);
+            else __syncthreads();
+            if (b < k) {
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    const double r0 = row[st.s_slot[j]], r1 = row[st.s_slot[j + 1]], r2 = row[st.s_slot[j + 2]],
+                                 r3 = row[st.s_slot[j + 3]];
+                    acc = fma(r0, st.s_val[j], acc);
+                    acc = fma(r1, st.s_val[j + 1], acc);
+                    acc = fma(r2, st.s_val[j + 2], acc);
+                    acc = fma(r3, st.s_val[j + 3], acc);
+                }
+                for (; j < cnt; ++j) acc = fma(row[st.s_slot[j]], st.s_val[j], acc);
+            }
+        }
+        if (b < k) {
+            int t = 0;
+            for (; t + 8 <= neta; t += 8) {
+                double u[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) u[g] = d.U[(long long)(t + g) * d.ldw + b];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) acc = fma(-u[g], s_beta[t + g], acc);
+            }
+            for (; t < neta; ++t) acc = fma(-d.U[(long long)t * d.ldw + b], s_beta[t], acc);
+            st_sc1(d.dxs + b, acc);
+            st_sc1(d.dx + i, acc);
+            if (KIND == DZG_STEP_PRIMAL) {
+                const double scaled = mu * xbi;
+                const double den = xi + scaled;
+                DzgCand2 cnd;
+                cnd.r = dzg_div(acc, den);
+                cnd.k = i;
+                cnd.h = -__builtin_inf();
+                if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+                if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0); // every storing wave drains its sc1 stores before the workgroup arrives
+    if (!chain_barrier(ctl, bar, gen)) return false;
+    // ---- dx on the positions of the basic slacks (k_sp_ftran_l): row lists in list order
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < d.m; r += gridDim.x * blockDim.x) {
+        const int p = d.rowpos[r];
+        if (p < 0) continue;
+        double acc = ld_sc1(d.acol + r);
+        const long long l0 = d.rptr[r];
+        const int n = d.bcnt[r];
+        double xi = 0.0, xbi = 0.0;
+        if (KIND == DZG_STEP_PRIMAL) {
+            xi = d.x[p];
+            xbi = d.xbar[p];
+        }
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const int c0 = d.bcol[l0 + i], c1 = d.bcol[l0 + i + 1], c2 = d.bcol[l0 + i + 2], c3 = d.bcol[l0 + i + 3];
+            const double v0 = d.bval[l0 + i], v1 = d.bval[l0 + i + 1], v2 = d.bval[l0 + i + 2], v3 = d.bval[l0 + i + 3];
+            const int s0 = d.bslot[c0], s1 = d.bslot[c1], s2 = d.bslot[c2], s3 = d.bslot[c3];
+            const double d0 = ld_sc1(d.dxs + s0), d1 = ld_sc1(d.dxs + s1), d2 = ld_sc1(d.dxs + s2),
+                         d3 = ld_sc1(d.dxs + s3);
+            acc = fma(-v0, d0, acc);
+            acc = fma(-v1, d1, acc);
+            acc = fma(-v2, d2, acc);
+            acc = fma(-v3, d3, acc);
+        }
+        for (; i < n; ++i) acc = fma(-d.bval[l0 + i], ld_sc1(d.dxs + d.bslot[d.bcol[l0 + i]]), acc);
+        st_sc1(d.dx + p, acc);
+        if (KIND == DZG_STEP_PRIMAL) {
+            const double scaled = mu * xbi;
+            const double den = xi + scaled;
+            DzgCand2 cnd;
+            cnd.r = dzg_div(acc, den);
+            cnd.k = p;
+            cnd.h = -__builtin_inf();
+            if (cnd.r > 0.0) best = dzg_better2(best, cnd);
+            if (dzg_noise_zero(den, xi, scaled, tau)) best.h = __builtin_inf();
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_sp_pre(const DzgDev d, unsigned long long *bar)
+{
+    __shared__ int s_slot[256];
+    __shared__ double s_val[256];
+    __shared__ double s_beta[R_];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_b[SP_LCAP];
+    __shared__ double s_coef[SP_LCAP];
+    __shared__ double s_gamma[R_];
+    __shared__ int s_cnt;
+    DzgCtl *ctl = d.ctl;
+    const DzgCand2 cj = reduce_partials(d.fpz_r, d.fpz_k, d.fpz_h, SP_NB_UPD);
+    const DzgCand2 ci = reduce_partials(d.fpx_r, d.fpx_k, d.fpx_h, SP_NB_UPD);
+    DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING) return;
+    unsigned long long gen = c.bar_gen;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const int m = d.m, tid = threadIdx.x;
+    int kind;
+    double mu;
+    if (!fast_status(ctl, c, lead, cj, ci, d.eps, m, false, kind, &mu)) return;
+    const int k = c.ncompact, neta = c.neta;
+    int p;
+    if (kind == DZG_STEP_PRIMAL) {
+        const int code = d.nbcode[cj.k];
+        if (lead) ctl->enter_code = code;
+        const SpStage st{s_slot, s_val, s_wcnt};
+        DzgCand2 best = dzg_cand2_none();
+        if (!sp_ftran_fused<DZG_STEP_PRIMAL>(d, ctl, bar, gen, code, k, neta, mu, c.tau, st, s_beta, best)) return;
+        best = dzg_block_best2(best);
+        if (tid == 0) {
+            st_sc1(d.rx_r + blockIdx.x, best.r);
+            st_sc1(d.rx_k + blockIdx.x, best.k);
+            st_sc1(d.rx_h + blockIdx.x, best.h);
+        }
+        __builtin_amdgcn_s_waitcnt(0); // (dx of the slack rows: later launches read it plainly)
+        if (!chain_barrier(ctl, bar, gen)) return;
+        DzgCand2 w = dzg_cand2_none();
+        for (int i = tid; i < (int)gridDim.x; i += blockDim.x) {
+            DzgCand2 o;
+            o.r = ld_sc1(d.rx_r + i);
+            o.k = ld_sc1(d.rx_k + i);
+            o.h = ld_sc1(d.rx_h + i);
+            w = dzg_better2(w, o);
+        }
+        const DzgCand2 cw = dzg_block_best2(w);
+        if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_UNBOUNDED)) { // src/simplex.rs:313
+            if (lead) ctl->bar_gen = gen;
+            return;
+        }
+        p = cw.k;
+        if (lead) ctl->leave_pos = p;
+    } else {
+        p = ci.k;
+    }
+    if (lead && gen != c.bar_gen) ctl->bar_gen = gen;
+    // ---- BTRAN: v = row p of B^-1 in row coordinates (k_sp_btran's body)
+    const int bp = d.sslot[p];
+    const int rl = bp >= 0 ? -1 : -1 - d.bcode[p];
+    const int stride = gridDim.x * blockDim.x;
+    const int gid = blockIdx.x * blockDim.x + tid;
+    if (d.lcnt && blockIdx.x == 0 && c.rl_listed != rl) { // live-entry lists: idempotent append
+        const int pend = c.rl_listed;
+        if (pend >= 0) {
+            for (long long e = d.rptr[pend] + tid; e < d.rptr[pend + 1]; e += blockDim.x) {
+                const int col = d.cidx[e];
+                const long long base = d.cptr[col];
+                const int n = d.lcnt[col];
+                for (int i = 0; i < n; ++i)
+                    if (d.lent[base + i].row == pend) {
+                        d.lent[base + i] = d.lent[base + n - 1];
+                        d.lcnt[col] = n - 1;
+                        break;
+                    }
+            }
+            __syncthreads();
+        }
+        if (rl >= 0)
+            for (long long e = d.rptr[rl] + tid; e < d.rptr[rl + 1]; e += blockDim.x) {
+                const int col = d.cidx[e];
+                const long long at = d.cptr[col] + d.lcnt[col];
+                DzgLiveEntry en;
+                en.row = rl;
+                en.pad_ = 0;
+                en.val = d.rval[e];
+                d.lent[at] = en;
+                d.lcnt[col] += 1;
+            }
+        if (tid == 0) ctl->rl_listed = rl;
+    }
+    for (int r = gid; r < m; r += stride)
+        if (d.dslot[r] < 0) d.v[r] = (r == rl) ? 1.0 : 0.0;
+    if (k == 0) return;
+    const long long e0 = bp >= 0 ? 0 : d.rptr[rl], e1 = bp >= 0 ? 1 : e0 + d.bcnt[rl];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (tid < R_) s_gamma[tid] = 0.0;
+    for (long long base = e0; base < e1; base += SP_LCAP) {
+        __syncthreads();
+        int total = 0;
+        if (bp >= 0) {
+            if (tid == 0) {
+                s_b[0] = bp;
+                s_coef[0] = 1.0;
+            }
+            total = 1;
+        } else {
+            const long long lim = (e1 - base) < SP_LCAP ? (e1 - base) : SP_LCAP;
+            for (long long i = tid; i < lim; i += blockDim.x) {
+                s_b[i] = d.bslot[d.bcol[base + i]];
+                s_coef[i] = -d.bval[base + i];
+            }
+            total = (int)lim;
+        }
+        if (tid == 0) s_cnt = total;
+        __syncthreads();
+        const int cnt = s_cnt;
+        if (tid < neta) {
+            double g = s_gamma[tid];
+            const double *ut = d.U + (long long)tid * d.ldw;
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const double u0 = ut[s_b[i]], u1 = ut[s_b[i + 1]], u2 = ut[s_b[i + 2]], u3 = ut[s_b[i + 3]];
+                g = fma(s_coef[i], u0, g);
+                g = fma(s_coef[i + 1], u1, g);
+                g = fma(s_coef[i + 2], u2, g);
+                g = fma(s_coef[i + 3], u3, g);
+            }
+            for (; i < cnt; ++i) g = fma(s_coef[i], ut[s_b[i]], g);
+            s_gamma[tid] = g;
+        }
+        int slot = 0;
+        for (int cc = gid; cc < k && slot < 4; cc += stride, ++slot) {
+            double a = acc[slot];
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const double x0 = d.binv[(long long)s_b[i] * d.ldb + cc], x1 = d.binv[(long long)s_b[i + 1] * d.ldb + cc],
+                             x2 = d.binv[(long long)s_b[i + 2] * d.ldb + cc], x3 = d.binv[(long long)s_b[i + 3] * d.ldb + cc];
+                a = fma(s_coef[i], x0, a);
+                a = fma(s_coef[i + 1], x1, a);
+                a = fma(s_coef[i + 2], x2, a);
+                a = fma(s_coef[i + 3], x3, a);
+            }
+            for (; i < cnt; ++i) a = fma(s_coef[i], d.binv[(long long)s_b[i] * d.ldb + cc], a);
+            acc[slot] = a;
+        }
+    }
+    __syncthreads();
+    int slot = 0;
+    for (int cc = gid; cc < k; cc += stride, ++slot) {
+        double a = slot < 4 ? acc[slot] : 0.0;
+        const int vr = d.drow[cc];
+        int t = 0;
+        for (; t + 8 <= neta; t += 8) {
+            double w[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) w[g] = d.W[(long long)(t + g) * d.ldw + cc];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) a = fma(-s_gamma[t + g], w[g], a);
+        }
+        for (; t < neta; ++t) a = fma(-s_gamma[t], d.W[(long long)t * d.ldw + cc], a);
+        d.v[vr] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sp_mid(const DzgDev d, unsigned long long *bar, int nrz)
+{
+    __shared__ int s_slot[256];
+    __shared__ double s_val[256];
+    __shared__ double s_beta[R_];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_ok, s_ci, s_cj;
+    DzgCtl *ctl = d.ctl;
+    const DzgCand2 cw = reduce_partials(d.rz_r, d.rz_k, d.rz_h, nrz); // (a primal step ignores them)
+    DzgCtl c = *ctl;
+    if (c.status != DZG_RUNNING) return;
+    unsigned long long gen = c.bar_gen;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const bool dual = c.kind == DZG_STEP_DUAL;
+    if (dual) {
+        if (!fast_ratio_outcome(ctl, c, lead, cw, DZG_INFEASIBLE)) return; // src/simplex.rs:325
+        const int epos = cw.k;
+        const int code = d.nbcode[epos];
+        if (lead) {
+            ctl->enter_pos = epos;
+            ctl->enter_code = code;
+        }
+        c.enter_pos = epos;
+        c.enter_code = code;
+        const SpStage st{s_slot, s_val, s_wcnt};
+        DzgCand2 unused = dzg_cand2_none();
+        if (!sp_ftran_fused<DZG_STEP_DUAL>(d, ctl, bar, gen, code, c.ncompact, c.neta, c.mu, c.tau, st, s_beta, unused))
+            return;
+        __builtin_amdgcn_s_waitcnt(0);
+        if (!chain_barrier(ctl, bar, gen)) return; // dx is complete: the books read it at the leaving position
+        if (lead) ctl->bar_gen = gen;
+    }
+    if (blockIdx.x != 0) return;
+    // ---- the pivot's books (k_sp_pivot's body, workgroup 0)
+    if (threadIdx.x == 0) {
+        const int p = c.leave_pos, r = c.enter_pos;
+        const int vi = d.basis[p], vj = d.nonbasis[r];
+        s_ci = d.bcode[p];
+        s_cj = d.nbcode[r];
+        const double dxp = dual ? ld_sc1(d.dx + p) : d.dx[p];
+        s_ok = sp_pivot_books(ctl, c, d.m, d.q, p, r, c.neta, vi, vj, s_ci, s_cj, d.x, d.xbar, d.z, d.zbar, d.dx, d.dz,
+                              d.basis, d.nonbasis, d.var_col, d.drow, d.dslot, d.sslot, d.spos, d.bslot, d.rowpos,
+                              d.plist, d.pslot, d.cptr, d.log_kind, d.log_enter, d.log_leave, d.log_mu,
+                              d.log_margin, d.log_cap, d.bcode, d.nbcode, d.pcode, d.lcnt != nullptr, dxp);
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const int ci = s_ci, cj = s_cj;
+    if (ci >= 0)
+        for (long long e = d.cptr[ci] + threadIdx.x; e < d.cptr[ci + 1]; e += blockDim.x) {
+            const int row = d.ridx[e];
+            const long long l0 = d.rptr[row];
+            const int n = d.bcnt[row];
+            for (int i = 0; i < n; ++i)
+                if (d.bcol[l0 + i] == ci) {
+                    d.bcol[l0 + i] = d.bcol[l0 + n - 1];
+                    d.bval[l0 + i] = d.bval[l0 + n - 1];
+                    break;
+                }
+            d.bcnt[row] = n - 1;
+        }
+    __syncthreads();
+    if (cj >= 0)
+        for (long long e = d.cptr[cj] + threadIdx.x; e < d.cptr[cj + 1]; e += blockDim.x) {
+            const int row = d.ridx[e];
+            const int n = d.bcnt[row];
+            d.bcol[d.rptr[row] + n] = cj;
+            d.bval[d.rptr[row] + n] = d.cval[e];
+            d.bcnt[row] = n + 1;
+        }
+    if (d.lcnt && cj < 0) {
+        const int re = -1 - cj;
+        for (long long e = d.rptr[re] + threadIdx.x; e < d.rptr[re + 1]; e += blockDim.x) {
+            const int col = d.cidx[e];
+            const long long base = d.cptr[col];
+            const int n = d.lcnt[col];
+            for (int i = 0; i < n; ++i)
+                if (d.lent[base + i].row == re) {
+                    d.lent[base + i] = d.lent[base + n - 1];
+                    d.lcnt[col] = n - 1;
+                    break;
+                }
+        }
+    }
+}
+
+// workgroups of the fused kernels the runtime places on one CU (0: none fits)
+int dzg_sp_fused_resident_per_cu(void)
+{
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_sp_pre, 256, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_sp_mid, 256, 0) != hipSuccess) return 0;
+    return a < b ? a : b;
+}
+
 // ---------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------
@@ -1075,6 +1538,18 @@ void dzg_launch_sp_flush(const DzgDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_sp_flush_mfma, dim3((kmax + 63) / 64, (kmax + 63) / 64), dim3(256), 0, st,
                        d.ctl, d.binv, d.ldb, d.U, d.ldw, d.W, d.ldw);
     hipLaunchKernelGGL(k_sp_flush_done, dim3(1), dim3(1), 0, st, d.ctl, ((kmax + 63) / 64) * 64);
+}
+
+int dzg_sp_grid(int m) { return sp_grid(m); }
+
+void dzg_launch_sp_pre(const DzgDev &d, unsigned long long *bar, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sp_pre, dim3(sp_grid(d.m)), dim3(256), 0, st, d, bar);
+}
+
+void dzg_launch_sp_mid(const DzgDev &d, unsigned long long *bar, int nrz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sp_mid, dim3(sp_grid(d.m)), dim3(256), 0, st, d, bar, nrz);
 }
 
 void dzg_launch_sp_ref_copy(const DzgDev &d, int k, const double *Xinv, long long ldx, hipStream_t st)

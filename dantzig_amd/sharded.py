@@ -54,6 +54,18 @@ class ShardedSolver(core.Solver):
                          shard_rows=1 if (shard_rows and lp.a is not None and world > 1) else 0, **opts)
         self.record_doubles = int(_ffi.lib().dzg_shard_record_doubles(self._h))
 
+    def row_range(self) -> tuple[int, int]:
+        """The rows of x / xbar this rank keeps while a row-sharded solve runs (shard_rows: slices of
+        ceil16(ceil(m / world)) rows, include/dantzig_amd.h); everything otherwise.  dzg_shard_run and
+        the lockstep loop complete x on every rank when they return; a host that drives the phases
+        itself reads each rank's own rows."""
+        m = self._lp.m
+        if not getattr(self._opts, "shard_rows", 0):
+            return 0, m
+        per = max(16, (-(-m // self.world) + 15) // 16 * 16)
+        lo = min(m, self.rank * per)
+        return lo, min(m, lo + per)
+
     def upload_columns(self, begin: int, end: int, a_block) -> None:
         """Columns [begin, end) of A (an (m, end - begin) array) of a replicated solver."""
         a_cm = np.ascontiguousarray(np.asarray(a_block, dtype=np.float64).T)

@@ -456,7 +456,9 @@ typedef struct {
  *                       mc = 0 with replicate_matrix)
  *   [80 + mc .. )       row p of the compact inverse Binv0, as many entries as the record holds
  * dzg_shard_record_doubles is the largest record (room for a row of m entries); dzg_shard_run sends
- * what the current compact width needs. */
+ * what the current compact width needs.  A host that drives the phases itself keeps the records of
+ * exchange 1 intact until phase 3 has been enqueued and run (phase 3 reads the leaving row of a dual
+ * step and the entering column of a primal step from them): two receive buffers. */
 int64_t dzg_shard_record_doubles(const dzg_solver *s);
 int dzg_shard_phase1(dzg_solver *s, double *send_dev);
 int dzg_shard_phase2(dzg_solver *s, const double *recv_dev, double *send_dev);

@@ -287,6 +287,38 @@ def test_config5_first_pivots_are_the_strict_log(core, config5):
     assert np.array_equal(np.sort(np.concatenate([res.basis, res.nonbasis])), np.arange(NS5 + M5))
 
 
+def test_config5_first_pivots_are_the_cpu_oracles(core, config5):
+    """pivots of config 5 that the CPU ORACLE holds -- the blocked twin of the C
+    restatement (oracle/dzg_oracle_blocked.c: Matrix::factorize with the same operations on every
+    element in the same order, bit-equal factors, tests/test_oracle_kats.py) ran the first pivots of
+    32768 x 65536 seed 1005 in the build container, 25 minutes of six cores each: two dense LUs of
+    32768 rows per pivot, the matrix handed over in the oracle's dense-input format
+    (tests/golden/oracle_blocked_pivots_1005_32768x65536.json, make_oracle_first_pivots.py
+    --blocked --dense-input).  STRICT -- the reference's arithmetic on the GPU -- takes them with mu
+    bit for bit, FAST pivot for pivot with mu to 1e-9; the committed HIP-STRICT log of 80 pivots
+    (test above) starts with them."""
+    import json
+    import os
+
+    fx = _oracle_fixture("blocked", SEED5, M5, NS5)
+    assert fx is not None and len(fx["kind"]) >= 2
+    n = len(fx["kind"])
+    want = list(zip(fx["kind"], fx["entering"], fx["leaving"]))
+    a, b, c = config5
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    n_strict = min(n, 2)                                                  # (12.7 s per STRICT pivot here)
+    strict = core.solve(lp, numerics=core.STRICT, max_iter=n_strict)
+    assert [(k, e, l) for k, e, l, _ in strict.pivots] == want[:n_strict]
+    assert [p[3] for p in strict.pivots] == fx["mu"][:n_strict]           # bit for bit
+    fast = core.solve(lp, numerics=core.FAST, max_iter=n)
+    assert [(k, e, l) for k, e, l, _ in fast.pivots] == want
+    assert np.allclose([p[3] for p in fast.pivots], fx["mu"], rtol=1e-9, atol=0)
+    assert fast.near_ties == 0
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pivots_1005_32768x65536.json")) as f:
+        hip = json.load(f)
+    assert list(zip(hip["kind"], hip["entering"], hip["leaving"]))[:n] == want
+
+
 def test_config5_column_sharded_over_8_ranks_partitioned(core, config5):
     """BASELINE config 5 as it is stated: 32768 x 65536 column-block PARTITIONED over 8 ranks (a
     rank holds its 8192 columns only -- 2.1 GB -- the entering column travels in the exchange

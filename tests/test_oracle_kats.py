@@ -260,3 +260,40 @@ def test_pivot_fixtures_at_benchmark_size_agree():
             assert lit[key][:n] == blk[key][:n], (m, key)
         checked += 1
     assert checked >= 1
+
+
+def test_dense_input_format_is_the_same_oracle():
+    """ora_simplex with row_idx == NULL reads the structural block as a dense column-major array with
+    implicit unit slack columns (oracle/dzg_oracle.h): the entries it visits are the CSC's -- exact
+    zeros skipped, ascending rows -- so pivots, mu and the state vectors are bit-equal in the two
+    formats (continuous data with planted zeros, small integers).  The format exists for fixtures at
+    sizes whose 64-bit CSC does not fit the build container (config 5: 34 GB)."""
+    import ctypes as C
+
+    from dantzig_amd import core
+    from tests.lp_families import make_lp
+
+    cases = []
+    for seed, m, ns in [(5, 40, 90), (6, 64, 64), (7, 33, 100)]:
+        a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+        a = np.array(a)
+        a[np.abs(a) < 0.05] = 0.0
+        cases.append((a, b, c))
+    cases += [make_lp(seed, 1, 10, 40) for seed in range(300, 306)]
+    for a, b, c in cases:
+        m, ns = a.shape
+        want = ora.simplex_solve(ora.stdform_from_dense(a, b, c), max_iter=5000)
+        val = np.ascontiguousarray(a.T)
+        basis, nonbasis = np.arange(ns, ns + m, dtype=np.int64), np.arange(ns, dtype=np.int64)
+        x, z = b.astype(np.float64).copy(), -c.astype(np.float64)
+        xbar, zbar = np.ones(m), np.ones(ns)
+        cc, cp = np.concatenate([c.astype(np.float64), np.zeros(m)]), np.zeros(1, dtype=np.int64)
+        st = ora._Simplex(m, ns + m, ora._p(cp), None, ora._p(val), ora._p(cc), 0.0, ora._p(basis),
+                          ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
+        log = (ora._Pivot * 5000)()
+        it = C.c_int64(0)
+        status = ora.lib().ora_simplex_solve(C.byref(st), C.c_int64(5000), C.byref(it), log, C.c_int64(5000))
+        got = [(log[i].kind, log[i].entering, log[i].leaving, log[i].mu) for i in range(it.value)]
+        assert (ora.STATUS[status], it.value) == (want.status, want.iterations)
+        assert got == want.pivots
+        assert np.array_equal(x, want.x) and np.array_equal(z, want.z) and np.array_equal(basis, want.basis)

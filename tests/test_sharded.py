@@ -357,7 +357,7 @@ def _hip():
     return hip
 
 
-def _gpu_phase_worker(rank, world, port, seed, m, ns, out):
+def _gpu_phase_worker(rank, world, port, seed, m, ns, out, shard_rows=False):
     """One rank = one OS process with its own solver on the one GPU.  The host drives
     dzg_shard_phase1 / 2 / 3 itself and moves the records with torch.distributed over gloo (device
     -> host -> all-gather -> device): the product's phase kernels in a real multi-process run."""
@@ -378,45 +378,53 @@ def _gpu_phase_worker(rank, world, port, seed, m, ns, out):
         ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)   # this rank's columns only
         lp = core.CoreLP.from_inequality_block(ab, bb, cb, begin, end)
         hip = _hip()
-        with ShardedSolver(lp, rank, world, poll_interval=1) as s:
+        with ShardedSolver(lp, rank, world, poll_interval=1, shard_rows=shard_rows) as s:
             nrec = s.record_doubles
-            send, recv = C.c_void_p(), C.c_void_p()
+            lo, hi = s.row_range()
+            # (two receive buffers: phase 3 of a row-sharded rank still reads the records of exchange 1)
+            send, recv, recv2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
             assert hip.hipMalloc(C.byref(send), 8 * nrec) == 0
             assert hip.hipMalloc(C.byref(recv), 8 * nrec * world) == 0
+            assert hip.hipMalloc(C.byref(recv2), 8 * nrec * world) == 0
             h_send = torch.zeros(nrec, dtype=torch.float64)
             h_recv = torch.zeros(nrec * world, dtype=torch.float64)
 
-            def exchange():
+            def exchange(to):
                 assert hip.hipMemcpy(h_send.data_ptr(), send, 8 * nrec, 2) == 0      # device -> host
                 all_gather_records(h_send, h_recv)
-                assert hip.hipMemcpy(recv, h_recv.data_ptr(), 8 * nrec * world, 1) == 0  # host -> device
+                assert hip.hipMemcpy(to, h_recv.data_ptr(), 8 * nrec * world, 1) == 0  # host -> device
 
             assert s.set_budget(0) == "running"
             status, pivots = "running", 0
             while status == "running" and pivots < 20000:
                 s.phase1(send.value)
-                exchange()
+                exchange(recv)
                 s.phase2(recv.value, send.value)
-                exchange()
-                s.phase3(recv.value)
+                exchange(recv2)
+                s.phase3(recv2.value)
                 status, pivots = s.poll()
             res = s.result()
             hip.hipFree(send)
             hip.hipFree(recv)
-        out.put((rank, status, res.pivots, res.x.tolist(), res.objective))
+            hip.hipFree(recv2)
+        # (a host that drives the phases itself gets no gather of x: each rank answers for its rows)
+        out.put((rank, status, res.pivots, (lo, hi, res.x[lo:hi].tolist()), res.objective))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,seed,m,ns", [(2, 45, 96, 200), (3, 46, 64, 150)])
-def test_sharded_processes_on_one_gpu_exchange_over_gloo(world, seed, m, ns):
+@pytest.mark.parametrize("world,seed,m,ns,shard_rows", [(2, 45, 96, 200, False), (3, 46, 64, 150, False),
+                                                        (3, 47, 96, 230, True)])
+def test_sharded_processes_on_one_gpu_exchange_over_gloo(world, seed, m, ns, shard_rows):
     """The column-sharded device path as SEVERAL OS PROCESSES (one rank each, all on this one GPU),
     the host driving dzg_shard_phase1 / 2 / 3 and exchanging the records with torch.distributed
     (gloo): every rank holds only its own column block (partitioned storage, a_is_block), the
     entering column travels in the records.  Every rank must take the oracle's pivots and hold the
     single-GPU FAST solve's numbers bit for bit.  (RCCL refuses two ranks on one device; the RCCL loop
-    itself runs with one rank in test_rccl_single_rank_loop.)"""
+    itself runs with one rank in test_rccl_single_rank_loop.)  shard_rows: the same with the basis side
+    sharded by rows (csrc/k_rowshard.hip) -- the records carry a row of the inverse at their full
+    width, each rank answers for its own rows of x."""
     import torch.multiprocessing as mp
 
     from dantzig_amd import core
@@ -428,7 +436,7 @@ def test_sharded_processes_on_one_gpu_exchange_over_gloo(world, seed, m, ns):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_phase_worker, args=(r, world, port, seed, m, ns, out))
+    procs = [ctx.Process(target=_gpu_phase_worker, args=(r, world, port, seed, m, ns, out, shard_rows))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -441,7 +449,10 @@ def test_sharded_processes_on_one_gpu_exchange_over_gloo(world, seed, m, ns):
         assert status == "optimal"
         assert [(k, e, l) for k, e, l, _ in pivots] == [(k, e, l) for k, e, l, _ in want.pivots]
         assert [tuple(p) for p in pivots] == [tuple(p) for p in single.pivots]   # mu too, exactly
-        assert x == single.x.tolist() and objective == single.objective
+        lo, hi, own = x
+        assert own == single.x[lo:hi].tolist()
+        if not shard_rows:
+            assert (lo, hi) == (0, m) and objective == single.objective
 
 
 @pytest.mark.gpu
