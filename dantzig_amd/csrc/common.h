@@ -408,7 +408,7 @@ struct DzgDev {
                          // (DZG_FTRAN_VARIANT), -1: nontemporal from k = ftran_nt_k on, plain below
     int ftran_nt_k;      // 8 m k bytes of inverse beyond 1.5 x the 256-MB Infinity Cache
     int fold_k;          // k_chain_post finishes the row-wise pricing pass itself while k stays below
-                         // this (few row groups: few partial sums per column); DZG_CHAIN_FOLD_K
+                         // this (default: always; DZG_CHAIN_FOLD_K is the A/B switch)
 };
 
 #ifdef __HIPCC__

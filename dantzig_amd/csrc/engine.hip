@@ -386,7 +386,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         d.ftran_nt_k = kk > 2e9 ? 2000000000 : (int)kk;
         if (d.ftran_nt_k < 513) d.ftran_nt_k = 513;
     }
-    d.fold_k = 256;
+    d.fold_k = 0x7fffffff;
     if (const char *fk = std::getenv("DZG_CHAIN_FOLD_K")) d.fold_k = std::atoi(fk);
     d.world = o.world > 1 ? o.world : 1;
     d.rank = d.world > 1 ? o.rank : 0;

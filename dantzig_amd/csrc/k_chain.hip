@@ -560,7 +560,36 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
         double zr, zbr, dzr, dxp;
         int G = (k + 1 + DZG_PR_BATCH - 1) / DZG_PR_BATCH; // row groups of the pricing pass (FOLD)
         G = G > DZG_PR_GMAX ? DZG_PR_GMAX : G;
-        if (!SHARD && fold && has_col) dz_k = chain_fold_dz(d, nbcode_k, G);
+        if (!SHARD && fold) {
+            // this workgroup's (position, row group) partial sums, fetched by ALL its threads in one
+            // trip through LDS (the gathered column's buffer is free until FTRAN); the owner of a
+            // position then adds its G values in group order -- chain_fold_dz's sum, without 32
+            // loads queuing behind one thread
+            const int ncols = q1 - q0;
+            int *s_code = reinterpret_cast<int *>(s_dx); // (CH_THREADS doubles: room for 512 codes)
+            if (has_col) s_code[tid] = nbcode_k;
+            __syncthreads();
+            if ((long long)ncols * G <= CH_AGCAP) {
+                for (int idx = tid; idx < ncols * G; idx += CH_THREADS) {
+                    const int g = idx / ncols, pl = idx - g * ncols;
+                    const int code = s_code[pl];
+                    s_ag[idx] = code >= 0 ? d.ppart[(long long)g * d.ldt + (code - d.col0)] : 0.0;
+                }
+                __syncthreads();
+                if (has_col) {
+                    if (nbcode_k < 0) {
+                        dz_k = chain_fold_dz(d, nbcode_k, G);
+                    } else {
+                        double sum = 0.0;
+                        for (int g = 0; g < G; ++g) sum = sum + s_ag[g * ncols + tid];
+                        dz_k = -sum;
+                    }
+                }
+                __syncthreads(); // (s_ag and s_dx are about to be reused)
+            } else if (has_col) {
+                dz_k = chain_fold_dz(d, nbcode_k, G);
+            }
+        }
         if (kind == DZG_STEP_DUAL) {
             const int dr0 = tid < k ? d.drow[tid] : -1;
             const int dr1 = tid + CH_THREADS < k ? d.drow[tid + CH_THREADS] : -1;

@@ -134,8 +134,7 @@ int dzg_price_rows_groups(void) { return PR_GMAX; }
 // pass itself (k_chain_post, FOLD) and the finishing launch is left out
 int dzg_price_rows_certain(const DzgDev &d, int kernel)
 {
-    // (... and few row groups: beyond k = fold_k a column's 32 partial sums cost the 96 threads that
-    // own a workgroup's columns more than the finishing launch's 65 536 threads, measured)
+    // (fold_k: an A/B switch, DZG_CHAIN_FOLD_K; the default is "whenever the pass is row-wise")
     return !d.csc && d.At && d.q > 0 && resolve(kernel) == DZG_PRICE_TREE && d.k_hint > 0 &&
            d.k_hint < d.rows_T && d.k_hint < d.fold_k;
 }

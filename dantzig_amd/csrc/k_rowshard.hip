@@ -168,14 +168,14 @@ __device__ __forceinline__ void rs_ftran_prep(const DzgDev &d, int code, const d
         }
         const double acc = fast_beta_dot(wt, a, d.m);
         if (threadIdx.x == 0) d.beta[b] = acc;
-    } else if (b == R_) {
-        if (code < 0) {
-            const int rr = -1 - code;
-            for (int c = threadIdx.x; c < k; c += blockDim.x) d.ag[c] = (d.drow[c] == rr) ? 1.0 : 0.0;
-        } else {
-            for (int c = threadIdx.x; c < k; c += blockDim.x) d.ag[c] = a[d.drow[c]];
-        }
-        if (threadIdx.x == 0 && (k & 1)) d.ag[k] = 0.0;
+    } else {
+        // the gather to compact coordinates, spread over the workgroups behind the beta ones (one
+        // workgroup took 20 us for k = 16 384: each entry is two dependent loads)
+        const int nb = (int)gridDim.x - R_, stride = nb * (int)blockDim.x;
+        const int rr = -1 - code;
+        for (int c = (b - R_) * (int)blockDim.x + (int)threadIdx.x; c < k; c += stride)
+            d.ag[c] = code < 0 ? ((d.drow[c] == rr) ? 1.0 : 0.0) : a[d.drow[c]];
+        if (b == R_ && threadIdx.x == 0 && (k & 1)) d.ag[k] = 0.0;
     }
 }
 
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_rs_select(const DzgDev d, const double 
         }
         rows = true;
     }
-    if (prep) {
+    if (prep) { // (every workgroup takes part: beta | gather)
         rs_ftran_prep(d, prep_code, a, neta, k);
         return;
     }
@@ -373,27 +373,45 @@ __global__ __launch_bounds__(256) void k_rs_gemv(const DzgDev d, const double *_
 //   column-wise (k_price_tree): lane l the rows 128 t + 2 l, + 1 of every tile t, one fma chain, the
 //     64 partial sums folded by an xor-shuffle tree.
 // ---------------------------------------------------------------------------------
+// (called by ALL 256 threads of the workgroup; the result is valid in the lanes of wave 0)
+#define RS_TILE 2048
 __device__ __forceinline__ double rs_price_one(const DzgDev &d, const double *__restrict__ a, int k,
                                                int lcode, int lane)
 {
     if (d.At && d.rows_T > 0 && k < d.rows_T) {
+        // The chains are fma after fma in a fixed order; what need not wait in line are the loads
+        // (coefficient, row index, then the column's entry: two dependent trips per term, 34 us for
+        // k = 16 384 when one wave did it all).  The whole workgroup stages a tile of (coefficient,
+        // entry) pairs in LDS, the G lanes of wave 0 then run their chains out of LDS.
+        __shared__ double s_cf[RS_TILE], s_av[RS_TILE];
         int G = (k + 1 + DZG_PR_BATCH - 1) / DZG_PR_BATCH;
         G = G > DZG_PR_GMAX ? DZG_PR_GMAX : G;
         const int nrows = k + (lcode < 0 ? 1 : 0);
+        const int tid = threadIdx.x;
         double acc = 0.0;
-        if (lane < G)
-            for (int c = lane; c < nrows; c += G) {
+        for (int c0 = 0; c0 < nrows; c0 += RS_TILE) { // (block-uniform trip count)
+            __syncthreads();
+            for (int i = tid; i < RS_TILE && c0 + i < nrows; i += blockDim.x) {
+                const int c = c0 + i;
                 const int row = c < k ? d.drow[c] : -1 - lcode;
-                const double coef = c < k ? d.vc[c] : 1.0;
-                acc = fma(coef, a[row], acc);
+                s_cf[i] = c < k ? d.vc[c] : 1.0;
+                s_av[i] = a[row];
             }
+            __syncthreads();
+            if (tid < G) {
+                // this lane's terms inside the tile: c = lane, lane + G, ... (global numbering)
+                int c = c0 + ((tid - c0 % G) % G + G) % G;
+                const int cend = c0 + RS_TILE < nrows ? c0 + RS_TILE : nrows;
+                for (; c < cend; c += G) acc = fma(s_cf[c - c0], s_av[c - c0], acc);
+            }
+        }
         double sum = 0.0;
         for (int g = 0; g < G; ++g) sum = sum + __shfl(acc, g, DZG_WAVE);
         return -sum;
     }
     const int m = d.m, ntiles = (m + 127) / 128;
     double acc = 0.0;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < (threadIdx.x < 64 ? ntiles : 0); ++t) {
         const int row = t * 128 + 2 * lane;
         const bool inside = row < m; // (row m of a column is zero: the matrix's padding, the record's)
         const double ax = inside ? a[row] : 0.0, ay = inside ? a[row + 1] : 0.0;
@@ -422,16 +440,13 @@ __global__ __launch_bounds__(256) void k_rs_books(const DzgDev d, const DzgPivot
     double dzr = c.dz_r;
     if (c.kind == DZG_STEP_PRIMAL) { // (a dual step's came with the winner's record)
         const int code = c.enter_code;
-        if (threadIdx.x < 64) {
-            double v0;
-            if (code < 0) { // a slack position: every rank priced the unit column itself
-                v0 = d.dz[c.enter_pos];
-            } else {
-                v0 = rs_price_one(d, rs_col(d, code, xrecv1, c.enter_src), c.ncompact, c.leave_code,
-                                  (int)threadIdx.x);
-            }
-            if (threadIdx.x == 0) s_dzr = v0;
-        }
+        double v0;
+        if (code < 0) // a slack position: every rank priced the unit column itself
+            v0 = d.dz[c.enter_pos];
+        else          // (all 256 threads: the terms are staged through LDS; valid in wave 0)
+            v0 = rs_price_one(d, rs_col(d, code, xrecv1, c.enter_src), c.ncompact, c.leave_code,
+                              (int)(threadIdx.x & 63));
+        if (threadIdx.x == 0) s_dzr = v0;
         __syncthreads();
         dzr = s_dzr;
     }

@@ -10,6 +10,7 @@ src/simplex.rs:274-306,308-330 decides -- (kind, entering, leaving) -- with mu* 
 iteration and the seconds of CPU the pivot took on one core of the machine that ran this.
 
   python3 tests/golden/make_oracle_first_pivots.py seed m ns pivots [--blocked] [--resume] [--dense-input]
+                                                   [--sparse-per-col N]
   (BASELINE config 3: 1003 8192 16384 8  -- about 6.5 minutes per pivot)
 
 --blocked: the twin library (oracle/dzg_oracle_blocked.c: Matrix::factorize applied block by
@@ -41,8 +42,28 @@ if __name__ == "__main__":
     the_lib = ora.blocked_lib() if blocked else ora.lib()
     path = os.path.join(ROOT, "tests", "golden",
                         f"oracle_{'blocked' if blocked else 'first'}_pivots_{seed}_{m}x{ns}.json")
-    a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
-    if "--dense-input" in sys.argv:
+    per_col = int(sys.argv[sys.argv.index("--sparse-per-col") + 1]) if "--sparse-per-col" in sys.argv else 0
+    if per_col > 0:
+        # generator G2 (BASELINE config 4): the reference's own CscMatrix over all columns, unit slack
+        # columns appended; the oracle densifies the basis like the reference does (two m x m LUs)
+        path = path.replace(".json", f"_csc{per_col}.json")
+        cp, ri, val_s, b, c = core.gen_sparse_lp(seed, m, ns, per_col)
+        n, q = ns + m, ns
+        col_ptr = np.concatenate([ora._i64(cp), ora._i64(cp[-1] + 1 + np.arange(m))])
+        row_idx = np.concatenate([ora._i64(ri), np.arange(m, dtype=np.int64)])
+        val = np.concatenate([ora._f64(val_s), np.ones(m)])
+        basis, nonbasis = np.arange(ns, ns + m, dtype=np.int64), np.arange(ns, dtype=np.int64)
+        x, z = ora._f64(b).copy(), -ora._f64(c)
+        xbar, zbar = np.ones(m), np.ones(q)
+        cc = np.concatenate([ora._f64(c), np.zeros(m)])
+        st = ora._Simplex(m, n, ora._p(col_ptr), ora._p(row_idx), ora._p(val), ora._p(cc), 0.0,
+                          ora._p(basis), ora._p(nonbasis), ora._p(x), ora._p(xbar), ora._p(z), ora._p(zbar))
+        a = None
+    else:
+        a, b, c = core.gen_dense_lp(seed=seed, m=m, n_struct=ns)
+    if per_col > 0:
+        pass
+    elif "--dense-input" in sys.argv:
         # the oracle's dense-structural input format (dzg_oracle.h, row_idx == NULL): the generator's
         # column-major block as it is, no 64-bit CSC beside it (34 GB at 32768 x 65536)
         n, q = ns + m, ns
@@ -80,7 +101,9 @@ if __name__ == "__main__":
     if os.path.exists(path):
         with open(path) as f:
             existing = len(json.load(f)["kind"])
-    out = {"seed": seed, "m": m, "n_struct": ns, "generator": "G1 (dantzig_amd.core.gen_dense_lp)",
+    out = {"seed": seed, "m": m, "n_struct": ns,
+           "generator": (f"G2 (dantzig_amd.core.gen_sparse_lp, {per_col} nonzeros per column)" if per_col > 0
+                         else "G1 (dantzig_amd.core.gen_dense_lp)"),
            "source": ("oracle/dzg_oracle.c + dzg_oracle_blocked.c (libdzg_oracle_blocked.so)" if blocked
                       else "oracle/dzg_oracle.c") + ", one ora_simplex_solve(max_iter=1) call per pivot",
            "kind": [], "entering": [], "leaving": [], "mu": [], "seconds_per_pivot": []}

@@ -508,12 +508,14 @@ def test_partitioned_sharding_refactorises(sparse):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("replicate", [False, True])
-def test_sharded_warm_start_from_a_non_slack_basis(replicate):
+@pytest.mark.parametrize("replicate,shard_rows", [(False, False), (True, False), (False, True), (True, True)])
+def test_sharded_warm_start_from_a_non_slack_basis(replicate, shard_rows):
     """A column-sharded solver created on a basis that is not the slack basis (the state a result
     handed back: dzg_lp.xbar / zbar) factorises it at its first run, the ranks exchanging their
     basic columns (partitioned) or after the last upload (replicated, a_is_block): the rest of the
-    solve is, bit for bit, the single-GPU solver's continuation from the same state."""
+    solve is, bit for bit, the single-GPU solver's continuation from the same state -- with the basis
+    side replicated and with it sharded by rows (each rank created from its own column block, as
+    `bench.py --gpus N` creates them)."""
     from dantzig_amd import core
     from dantzig_amd.sharded import ShardedSolver, col_range, run_lockstep
 
@@ -533,6 +535,7 @@ def test_sharded_warm_start_from_a_non_slack_basis(replicate):
             ab, bb, cb = core.gen_dense_lp_block(seed, m, ns, begin, end)
             lp = core.resumed_from(core.CoreLP.from_inequality_block(ab, bb, cb, begin, end), mid)
             solvers.append(ShardedSolver(lp, r, world, poll_interval=8, replicate=replicate,
+                                         shard_rows=shard_rows,
                                          stream=solvers[0].stream if solvers else 0))
         if replicate:
             for r, s in enumerate(solvers):
