@@ -28,6 +28,10 @@ import os
 import sys
 import time
 
+# (before anything loads an OpenMP runtime: the CPU baseline's at-size leg runs the oracle's blocked
+# twin on this many threads -- a GPU box gives one GPU's job 16 host cores)
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -48,7 +52,7 @@ MFMA_F64_DATASHEET_TFLOPS = 78.6  # AMD's datasheet figure for fp64 matrix (SURV
 CPU_RECORD = "tests/golden/oracle_first_pivots_1003_8192x16384.json"
 
 
-def _oracle_seconds_per_pivot(rows: int, cols: int, seed: int, pivots: int):
+def _oracle_seconds_per_pivot(rows: int, cols: int, seed: int, pivots: int, blocked: bool = False):
     from dantzig_amd import core
     from oracle import oracle as ora
 
@@ -56,20 +60,30 @@ def _oracle_seconds_per_pivot(rows: int, cols: int, seed: int, pivots: int):
     sf = ora.stdform_from_dense(a, b, c)
     del a
     t0 = time.perf_counter()
-    res = ora.simplex_solve(sf, max_iter=pivots, log_cap=pivots)
+    res = ora.simplex_solve(sf, max_iter=pivots, log_cap=pivots, blocked=blocked)
     dt = time.perf_counter() - t0
-    return dt / max(res.iterations, 1), res.iterations, dt
+    return dt / max(res.iterations, 1), res.iterations, dt, res.pivots
+
+
+CPU_AT_SIZE_MAX_ROWS = 8192
 
 
 def cpu_baseline(sample_rows: int, sample_cols: int, seed: int, pivots: int, rows: int,
-                 anchor_rows: int = 4096):
+                 anchor_rows: int = 0, at_size: tuple | None = None):
     """The oracle (C restatement of the reference algorithm: full dense LU of B and of B^T
-    every iteration) timed on THIS host, 1 core, on a bounded sample: `pivots` pivots at
-    `sample_rows` rows and ONE real pivot at `anchor_rows` rows (0: skip); `value` is the rate at
-    `rows` rows, extrapolated from the anchor with the exponent measured between the two."""
+    every iteration) timed on THIS host on a bounded sample.
+
+    `at_size` = (cols, seed, pivots): REAL pivots of the benchmark's own LP at its own size, by the
+    oracle's blocked twin (oracle/dzg_oracle_blocked.c: Matrix::factorize applied block by block
+    on several cores -- the same operations per element in the same order, its factors and pivots
+    bit-equal to the literal loop's, tests/test_oracle_kats.py) on OMP_NUM_THREADS threads; the
+    pivots it takes are compared with the committed fixture of the literal oracle.  `value` is then
+    that measured rate and `cores` the threads.  The literal single-core loop is timed beside it on
+    `pivots` pivots at `sample_rows` rows (and, with `anchor_rows`, one real pivot at that size, whose
+    measured exponent carries the one-core rate to the benchmark size)."""
     import math
 
-    spp, done, dt = _oracle_seconds_per_pivot(sample_rows, sample_cols, seed, pivots)
+    spp, done, dt, _ = _oracle_seconds_per_pivot(sample_rows, sample_cols, seed, pivots)
     rate = 1.0 / spp
     out = {
         "unit": "iterations/s", "cores": 1, "kind": "port",
@@ -78,23 +92,24 @@ def cpu_baseline(sample_rows: int, sample_cols: int, seed: int, pivots: int, row
         "host_cores_total": os.cpu_count(),
     }
     sample = (f"first {done} pivots of the {sample_rows}x{sample_cols} G1 LP (seed {seed}) on the C "
-              f"restatement of the reference (oracle/), {dt:.1f} s of CPU: {rate:.3f} it/s")
+              f"restatement of the reference (oracle/), one core, {dt:.1f} s of CPU: {rate:.3f} it/s")
     if anchor_rows and anchor_rows > sample_rows and rows >= anchor_rows:
-        spp_a, _, dt_a = _oracle_seconds_per_pivot(anchor_rows, 2 * anchor_rows, 1006, 1)
+        spp_a, _, dt_a, _ = _oracle_seconds_per_pivot(anchor_rows, 2 * anchor_rows, 1006, 1)
         expo = math.log(spp_a / spp) / math.log(anchor_rows / sample_rows)
         out["value"] = 1.0 / (spp_a * (rows / anchor_rows) ** expo)
         out["anchor"] = {"rows": anchor_rows, "seconds_per_pivot": spp_a, "pivots": 1,
                          "measured_exponent": expo}
         out["extrapolated"] = rows != anchor_rows
-        sample += (f"; one real pivot at {anchor_rows} rows: {dt_a:.1f} s; value = the rate at {rows} "
+        sample += (f"; one real pivot at {anchor_rows} rows: {dt_a:.1f} s; the one-core rate at {rows} "
                    f"rows EXTRAPOLATED from that pivot with the exponent measured between the two "
                    f"sizes on this host ({expo:.2f}; the flop model (4/3)m^3 says 3 and would give "
                    f"{out['flop_model_value']:.4f} it/s)")
     else:
         out["value"] = out["flop_model_value"]
         out["extrapolated"] = rows != sample_rows
-        sample += f"; value = that x ({sample_rows}/{rows})^3, the (4/3)m^3 flop model (no anchor pivot timed)"
-    out["sample"] = sample
+        sample += (f"; one-core rate at {rows} rows by the (4/3)m^3 flop model: that x "
+                   f"({sample_rows}/{rows})^3 (no anchor pivot timed)")
+    rec = None
     try:
         with open(os.path.join(ROOT, CPU_RECORD)) as f:
             rec = json.load(f)
@@ -106,7 +121,28 @@ def cpu_baseline(sample_rows: int, sample_cols: int, seed: int, pivots: int, row
             "where": "build container, 1 core (two other jobs on the machine), real pivots of the "
                      "8192x16384 seed-1003 LP", "source": CPU_RECORD}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
-        pass
+        rec = None
+    if at_size and rows <= CPU_AT_SIZE_MAX_ROWS:
+        cols_s, seed_s, pivots_s = at_size
+        spp_s, done_s, dt_s, log_s = _oracle_seconds_per_pivot(rows, cols_s, seed_s, pivots_s, blocked=True)
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        out["one_core"] = {"value": out["value"], "extrapolated": out["extrapolated"]}
+        out["value"] = 1.0 / spp_s
+        out["cores"] = threads
+        out["extrapolated"] = False
+        out["at_benchmark_size"] = {"rows": rows, "cols": cols_s, "seed": seed_s, "pivots": done_s,
+                                    "seconds": dt_s, "seconds_per_pivot": spp_s, "threads": threads,
+                                    "oracle": "blocked twin (oracle/dzg_oracle_blocked.c), bit-equal to the literal loop"}
+        if rec and rec.get("m") == rows and rec.get("seed") == seed_s and rec.get("n_struct") == cols_s:
+            n_cmp = min(done_s, len(rec["mu"]))
+            want = [(int(rec["kind"][i]), int(rec["entering"][i]), int(rec["leaving"][i]), float(rec["mu"][i]))
+                    for i in range(n_cmp)]
+            got = [(int(p[0]), int(p[1]), int(p[2]), float(p[3])) for p in log_s[:n_cmp]]
+            out["at_benchmark_size"]["pivots_equal_the_literal_oracles"] = n_cmp > 0 and got == want
+        sample = (f"VALUE: {done_s} real pivots of the benchmark's own LP ({rows}x{cols_s}, seed {seed_s}) by "
+                  f"the oracle's blocked twin on {threads} threads of this host, {dt_s:.1f} s: "
+                  f"{1.0 / spp_s:.4f} it/s.  Beside it, one core: " + sample)
+    out["sample"] = sample
     return out
 
 
@@ -609,9 +645,12 @@ def main() -> int:
                     help="run the column-sharded RCCL path even with one rank (rehearsal)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
     ap.add_argument("--cpu-sample-pivots", type=int, default=100)
-    ap.add_argument("--cpu-anchor-rows", type=int, default=4096,
-                    help="CPU baseline: also time ONE real oracle pivot at this many rows (~30-50 s of "
-                         "one core) to anchor the extrapolation to the benchmark size; 0 = skip")
+    ap.add_argument("--cpu-anchor-rows", type=int, default=0,
+                    help="CPU baseline: also time ONE real oracle pivot at this many rows on one core "
+                         "(~20 s at 4096) to anchor the one-core extrapolation to the benchmark size; 0 = skip")
+    ap.add_argument("--cpu-size-pivots", type=int, default=6,
+                    help="CPU baseline: real pivots of the benchmark's own LP at its own size by the oracle's "
+                         "blocked twin on 16 threads (3.4 s each at 8192 rows on a GPU box); 0 = skip")
     args = ap.parse_args()
 
     if args.refactor_child > 0:
@@ -705,8 +744,9 @@ def main() -> int:
         except Exception as exc:  # never lose the primary line to the secondary workload
             out.setdefault("secondary", {})["error"] = f"{type(exc).__name__}: {exc}"
     if not args.no_cpu_baseline:
+        at_size = (args.cols, args.seed, args.cpu_size_pivots) if args.cpu_size_pivots > 0 and not args.sparse_per_col else None
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, 2 * args.cpu_sample_rows, 1002,
-                                           args.cpu_sample_pivots, args.rows, args.cpu_anchor_rows)
+                                           args.cpu_sample_pivots, args.rows, args.cpu_anchor_rows, at_size)
     print(json.dumps(out))
     return 0
 

@@ -344,13 +344,14 @@ def bench_main(args, rank: int, world: int, local_rank: int) -> int:
         deep = run(dp["rows"], dp["cols"], dp["seed"], dp["steps"], dp["warmup"], replicate=False,
                    shard_rows=False, warm_k=dp["warm_k"])
         out["deep"]["basis_replicated"] = {k: deep[k] for k in sub}
-    if rank == 0 and not getattr(args, "no_cpu_baseline", False):
-        # the reference's algorithm on this box's host, one core, while the other ranks wait at the
-        # barrier below (bench.py: cpu_baseline)
+    if rank == 0 and world == 1 and not getattr(args, "no_cpu_baseline", False):
+        # the reference's algorithm on this box's host (bench.py: cpu_baseline) -- at N = 1 only: with
+        # more ranks the others would sit at the barrier below for it
         import bench
 
+        at_size = (args.cols, args.seed, args.cpu_size_pivots) if args.cpu_size_pivots > 0 else None
         out["cpu_baseline"] = bench.cpu_baseline(args.cpu_sample_rows, 2 * args.cpu_sample_rows, 1002,
-                                                 args.cpu_sample_pivots, args.rows, args.cpu_anchor_rows)
+                                                 args.cpu_sample_pivots, args.rows, args.cpu_anchor_rows, at_size)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
