@@ -342,6 +342,15 @@ def secondary_wanted(args) -> bool:
             and args.cols == 16384 and args.sparse_per_col == 0 and args.numerics == "fast")
 
 
+EVENT_STRIDE = 8  # pricing passes per timed one (opts.profile bits 16..23)
+
+
+def price_profile() -> int:
+    from dantzig_amd import _ffi
+
+    return (1 << _ffi.K_PRICE) | (EVENT_STRIDE << 16)
+
+
 PRICE_KERNELS = {"auto": "k_price_tree", "tree": "k_price_tree", "seq": "k_price_seq2",
                  "wave": "k_price_wave2"}
 
@@ -353,13 +362,19 @@ ROWS_M = 0
 def _pricing(r0, r1, kernel: str) -> dict:
     """Roofline block of the pricing kernel between two result snapshots."""
     ms = r1.kernel_ms["price"] - r0.kernel_ms["price"]
-    launches = r1.kernel_launches["price"] - r0.kernel_launches["price"]
-    nbytes = r1.price_bytes - r0.price_bytes
-    achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else float("nan")
+    timed = r1.kernel_launches["price"] - r0.kernel_launches["price"]
+    launches = r1.iterations - r0.iterations  # one pricing pass per pivot
+    nbytes = r1.price_bytes - r0.price_bytes  # (algorithmic, every pass of the region)
+    avg_ms = ms / max(timed, 1)
+    per_launch = nbytes / max(launches, 1)
+    achieved = (per_launch / 1e9) / (avg_ms / 1e3) if ms > 0 else float("nan")
     out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-           "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
-           "algorithmic_bytes_per_launch": nbytes / max(launches, 1)}
+           "avg_launch_us": 1e3 * avg_ms, "launches": launches, "launches_timed": timed,
+           "timing": ("HIP events (no system-scope fence) around every %d-th pricing pass of the region: "
+                      "an event pair between two 10-us kernels costs the GPU a few idle microseconds, "
+                      "5.7 each with default events (profiles/r04_chain_phase_clocks.txt)" % EVENT_STRIDE),
+           "algorithmic_bytes_per_launch": per_launch}
     if ROWS_T is not None:
         # dense matrix, AUTO pricing: the pass is chosen per pivot by the compact width k
         k0, k1 = r0.dense_columns, r1.dense_columns
@@ -434,7 +449,7 @@ def _late_regime(solver, r1, steps: int, late_pivots: int, kernel: str) -> dict:
             for k, label in names.items()}
         out["kernel_us_note"] = (f"HIP events around each kernel class over {n} further pivots "
                                  "(event overhead included; not part of any reported rate)")
-        solver.set_profile(1 << _ffi.K_PRICE)  # back to timing the pricing pass only
+        solver.set_profile(price_profile())  # back to timing the pricing pass only
     return out
 
 
@@ -477,7 +492,7 @@ def measure(rows, cols, seed, sparse_per_col, price_name, numerics_name, steps, 
         "k_price_seq2" if numerics_name == "strict" else PRICE_KERNELS[price_name])
     t_up = time.perf_counter()
     solver = core.Solver(lp, numerics=numerics, price_kernel=price,
-                         profile=1 << _ffi.K_PRICE, poll_interval=50,
+                         profile=price_profile(), poll_interval=50,
                          seven_launches=1 if SEVEN_LAUNCHES else 0)
     t_up = time.perf_counter() - t_up
     late = deep = whole = mfma = end = None
@@ -694,6 +709,8 @@ def main() -> int:
     late_pivots = 0 if (args.no_late or under_profiler()) else args.late_pivots
     global SEVEN_LAUNCHES
     SEVEN_LAUNCHES = bool(args.seven_launches)
+    global EVENT_STRIDE  # (a short timed region still gets a few timed passes)
+    EVENT_STRIDE = 8 if args.steps >= 64 else (4 if args.steps >= 16 else 1)
     deep_pivots = args.deep_pivots if (late_pivots > 0 and args.rows == 8192 and args.cols == 16384
                                        and args.sparse_per_col == 0) else 0
     whole = (args.whole_solve or (deep_pivots > 0 and args.numerics == "fast")) and not args.no_whole_solve

@@ -775,7 +775,10 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
     }
     if (o.profile) {
         s->ev.resize((size_t)o.poll_interval * DZG_K_COUNT * 2);
-        for (auto &e : s->ev) HIP_OK(hipEventCreate(&e));
+        // (timing only, read after the stream has been waited for: without the system-scope fence a
+        // default event carries -- 5.7 us of idle GPU per record between two 10-us kernels,
+        // profiles/r04_chain_phase_clocks.txt)
+        for (auto &e : s->ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     }
     HIP_OK(hipStreamSynchronize(s->st));
     HIP_OK(hipGetLastError());
@@ -786,17 +789,29 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
 
 // ---- one iteration, enqueued ------------------------------------------------------
 namespace {
+// opts.profile: the classes to time (low 16 bits; any negative value: all of them) and, in bits
+// 16..23, a sampling stride S > 1: only every S-th iteration of a batch is stamped
+static inline bool prof_on(const dzg_solver *s, int cls, int slot)
+{
+    const int p = s->opts.profile;
+    if (p == 0 || slot < 0) return false;
+    if (p < 0) return true;
+    const int stride = (p >> 16) & 0xff;
+    // (the last of each S: the first iteration of a batch starts on an empty queue)
+    return (p & (1 << cls)) && (stride <= 1 || slot % stride == stride - 1);
+}
+
 struct Prof {
     dzg_solver *s;
     int slot;
     void begin(int cls) const
     {
-        if (s->opts.profile & (1 << cls))
+        if (prof_on(s, cls, slot))
             hipEventRecord(s->ev[((size_t)slot * DZG_K_COUNT + cls) * 2], s->st);
     }
     void end(int cls) const
     {
-        if (s->opts.profile & (1 << cls))
+        if (prof_on(s, cls, slot))
             hipEventRecord(s->ev[((size_t)slot * DZG_K_COUNT + cls) * 2 + 1], s->st);
     }
 };
@@ -939,7 +954,7 @@ static void collect_profile(dzg_solver *s, int slots_real)
     if (!s->opts.profile) return;
     for (int slot = 0; slot < slots_real; ++slot)
         for (int cls = 0; cls < DZG_K_COUNT; ++cls) {
-            if (!(s->opts.profile & (1 << cls))) continue;
+            if (!prof_on(s, cls, slot)) continue;
             if (s->d.csc && !s->d.spb && s->d.world == 1 && !s->comm && cls != DZG_K_PRICE)
                 continue; // the single-GPU record path of a CSC solver only stamps pricing
             if (s->batch_chain && s->d.world == 1 && !s->comm &&
@@ -1487,7 +1502,7 @@ extern "C" int64_t dzg_shard_record_doubles(const dzg_solver *s) { return s ? s-
 // event stamps of the phase path: slot = s->prof_slot (< 0: none)
 static void phase_stamp(dzg_solver *s, int cls, int end)
 {
-    if (s->prof_slot >= 0 && (s->opts.profile & (1 << cls)))
+    if (prof_on(s, cls, s->prof_slot))
         hipEventRecord(s->ev[((size_t)s->prof_slot * DZG_K_COUNT + cls) * 2 + end], s->st);
 }
 

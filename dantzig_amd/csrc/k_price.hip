@@ -82,9 +82,20 @@ int dzg_price_partials(int kernel)
 }
 
 // partial count of the pass dzg_launch_price_fast(d, kernel) will run
+static int rl_grid(void)
+{
+    static const int g = [] {
+        const char *e = std::getenv("DZG_RL_GRID");
+        const int v = e ? std::atoi(e) : DZG_PRICE_CSC_BLOCKS;
+        return v < 1 ? 1 : (v > DZG_PRICE_CSC_BLOCKS ? DZG_PRICE_CSC_BLOCKS : v);
+    }();
+    return g;
+}
+
 int dzg_price_partials_dev(const DzgDev &d, int kernel)
 {
     if (!d.csc) return dzg_price_partials(kernel);
+    if (d.spb && d.lcnt && kernel != DZG_PRICE_SEQ) return rl_grid();
     return DZG_PRICE_CSC_BLOCKS;
 }
 
@@ -144,7 +155,7 @@ void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need
     if (d.csc) {
         if (d.spb && d.lcnt && kernel != DZG_PRICE_SEQ) { // sparse basis: the live entries only
             if (d.q > 0)
-                hipLaunchKernelGGL(k_price_csc_rl, dim3(DZG_PRICE_CSC_BLOCKS), dim3(256), 0, st, d.ctl,
+                hipLaunchKernelGGL(k_price_csc_rl, dim3(rl_grid()), dim3(256), 0, st, d.ctl,
                                    d.cptr, d.lcnt, d.lent, d.q, d.plist, d.pcode, d.nbcode, d.v,
                                    d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h, d.rl_work);
             return;

@@ -126,7 +126,10 @@ typedef struct {
     int64_t log_capacity;     /* pivots kept in the device log, default min(max_iter, 2^22) */
     int32_t poll_interval;    /* FAST: iterations enqueued between host status polls, default 32 */
     int32_t profile;          /* bit mask, bit (1 << DZG_K_*) set: time that kernel class with
-                                 HIP events (slower); 0 = no timing, -1 = every class    */
+                                 HIP events (slower); 0 = no timing, -1 = every class.
+                                 Bits 16..23: a sampling stride S > 1 -- only every S-th
+                                 iteration of a batch is stamped (an event pair costs a few
+                                 microseconds of idle GPU between two short kernels)     */
     /* Column sharding (one process per GPU).  This rank prices the structural columns
      * [col_begin, col_end); 0,0 = all.  See dzg_shard_* below. */
     int64_t col_begin, col_end;

@@ -1318,6 +1318,29 @@ def test_chain_and_seven_launches_are_the_same_solve(core):
     assert len(statuses) >= 3, statuses
 
 
+def test_kernel_timing_can_sample_every_nth_pivot(core):
+    """opts.profile bits 16..23: a sampling stride.  Event pairs cost idle GPU time between short
+    kernels, so bench.py times every 8th pricing pass only: the stamped launches are the last of
+    every 8 iterations of a batch, the timed classes the low 16 bits', and the solve is the solve
+    (timing changes nothing on the device)."""
+    from dantzig_amd import _ffi
+
+    a, b, c = core.gen_dense_lp(seed=4242, m=96, n_struct=200)
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    plain = core.solve(lp, numerics=core.FAST, max_iter=160, poll_interval=40)
+    every = core.solve(lp, numerics=core.FAST, max_iter=160, poll_interval=40, profile=1 << _ffi.K_PRICE)
+    some = core.solve(lp, numerics=core.FAST, max_iter=160, poll_interval=40,
+                      profile=(1 << _ffi.K_PRICE) | (8 << 16))
+    assert plain.iterations == every.iterations == some.iterations == 160
+    assert _same_solution(plain, every) and _same_solution(plain, some)
+    assert every.kernel_launches["price"] == 160
+    assert some.kernel_launches["price"] == 4 * 5  # slots 7, 15, 23, 31, 39 of each batch of 40
+    assert some.kernel_launches["update"] == 0 and some.kernel_ms["price"] > 0.0
+    avg_all = every.kernel_ms["price"] / 160
+    avg_some = some.kernel_ms["price"] / 20
+    assert 0.2 * avg_all < avg_some < 5 * avg_all
+
+
 def test_chain_follows_the_oracle_and_survives_stops_and_refactorisations(core):
     """The chain under everything a run can be cut by: budgets that end between its launches'
     iterations, near-tie stops (resumed), a refactorisation every 50 pivots -- against the
