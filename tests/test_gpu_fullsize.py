@@ -216,6 +216,37 @@ def test_config4_csc_pricing_is_the_reference_sum(core, sparse_lp):
     assert np.array_equal(dm[5000:], 0.0 + -v1[-1 - mix[5000:]])
 
 
+def test_config4_first_pivots_are_the_cpu_oracles(core, sparse_lp):
+    """the first pivots of the sparse 50 000 x 100 000 LP as the CPU
+    ORACLE takes them -- the blocked twin of the C restatement on the reference's own CscMatrix over
+    all columns, the basis densified like the reference does (src/linalg.rs:236-238): two dense LUs
+    of 50 000 rows, 2 x 20 GB, 75 minutes of six cores per pivot in the build container
+    (tests/golden/oracle_blocked_pivots_1004_50000x100000_csc50.json, make_oracle_first_pivots.py
+    --blocked --sparse-per-col 50).  FAST on the sparse-basis path (matrix CSC on the device,
+    live-entry pricing) takes them pivot for pivot with mu to 1e-9; STRICT -- the reference's
+    arithmetic on the GPU, the same two 50 000-row LUs -- the first one bit for bit."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "golden",
+                        f"oracle_blocked_pivots_{SEED4}_{M4}x{NS4}_csc{PER_COL4}.json")
+    assert os.path.exists(path), path
+    with open(path) as f:
+        fx = json.load(f)
+    n = len(fx["kind"])
+    assert n >= 1 and (fx["seed"], fx["m"], fx["n_struct"]) == (SEED4, M4, NS4)
+    want = list(zip(fx["kind"], fx["entering"], fx["leaving"]))
+    cp, ri, val, b, c = sparse_lp
+    lp = core.CoreLP.from_csc(M4, cp, ri, val, b, c)
+    fast = core.solve(lp, numerics=core.FAST, max_iter=n)
+    assert [(k, e, l) for k, e, l, _ in fast.pivots] == want
+    assert np.allclose([p[3] for p in fast.pivots], fx["mu"], rtol=1e-9, atol=0)
+    assert fast.near_ties == 0
+    strict = core.solve(lp, numerics=core.STRICT, max_iter=1)
+    assert [(k, e, l) for k, e, l, _ in strict.pivots] == want[:1]
+    assert strict.pivots[0][3] == fx["mu"][0]                             # bit for bit
+
+
 def test_config4_fast_run_invariants(core, sparse_lp):
     """1 000 pivots of FAST numerics on config 4 (matrix CSC on the device): basis / nonbasis stay
     a partition, the basic solution the engine carries satisfies A x_B + slack = b under scipy's
