@@ -224,7 +224,7 @@ def test_config4_first_pivots_are_the_cpu_oracles(core, sparse_lp):
     (tests/golden/oracle_blocked_pivots_1004_50000x100000_csc50.json, make_oracle_first_pivots.py
     --blocked --sparse-per-col 50).  FAST on the sparse-basis path (matrix CSC on the device,
     live-entry pricing) takes them pivot for pivot with mu to 1e-9; STRICT -- the reference's
-    arithmetic on the GPU, the same two 50 000-row LUs -- the first one bit for bit."""
+    arithmetic on the GPU, the same two 50 000-row LUs per pivot -- bit for bit."""
     import json
     import os
 
@@ -242,9 +242,9 @@ def test_config4_first_pivots_are_the_cpu_oracles(core, sparse_lp):
     assert [(k, e, l) for k, e, l, _ in fast.pivots] == want
     assert np.allclose([p[3] for p in fast.pivots], fx["mu"], rtol=1e-9, atol=0)
     assert fast.near_ties == 0
-    strict = core.solve(lp, numerics=core.STRICT, max_iter=1)
-    assert [(k, e, l) for k, e, l, _ in strict.pivots] == want[:1]
-    assert strict.pivots[0][3] == fx["mu"][0]                             # bit for bit
+    strict = core.solve(lp, numerics=core.STRICT, max_iter=n)
+    assert [(k, e, l) for k, e, l, _ in strict.pivots] == want
+    assert [p[3] for p in strict.pivots] == fx["mu"]                      # bit for bit
 
 
 def test_config4_fast_run_invariants(core, sparse_lp):
