@@ -378,7 +378,13 @@ def _pricing(r0, r1, kernel: str) -> dict:
     if ROWS_T is not None:
         # dense matrix, AUTO pricing: the pass is chosen per pivot by the compact width k
         k0, k1 = r0.dense_columns, r1.dense_columns
-        if max(k0, k1) < ROWS_T:
+        small_k = int(os.environ.get("DZG_PRICE_SMALL_K", "480"))
+        if max(k0, k1) + 50 < small_k:  # (the engine's bound on k for a batch of 50 pivots)
+            out["kernel"] = "k_price_rows_small"
+            out["bytes_model"] = ("fused row-wise pass: 8 (k+1) ldt (rows of the row-major copy) + 4 n_s (the "
+                                  "code -> position map) + 12 k + 32 q per launch (the row groups' partial sums "
+                                  "stay in LDS); k = %d..%d of %d rows" % (k0, k1, ROWS_M))
+        elif max(k0, k1) < ROWS_T:
             out["kernel"] = "k_price_rows<2> + k_price_rows_finish"
             out["bytes_model"] = ("row-wise pass: 8 (k+1) ldt (rows of the row-major copy) + 16 G ldt "
                                   "(partials of the G row groups, written and read) + 12 k + 32 q per "

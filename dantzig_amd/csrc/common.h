@@ -350,6 +350,8 @@ struct DzgDev {
     int *plist;        // [q] nonbasic positions holding structural variables (first nb_struct)
     int *pslot;        // [q] index into plist or -1
     int *pcode;        // [q] column code of the variable at plist[i] (the pricing waves' column list)
+    int *cpos;         // [col1 - col0] nonbasic position of structural column col0 + j, -1 while it is basic
+                       // (dense matrix, one GPU: k_price_rows_small walks column tiles, not positions)
     double *fpx_r, *fpz_r, *rx_r, *rz_r; // partial candidates (ratios)
     int *fpx_k, *fpz_k, *rx_k, *rz_k;    // partial candidates (positions)
     double *fpx_h, *fpz_h, *rx_h, *rz_h; // partial candidates (runner-up ratios, DzgCand2::h)
@@ -439,7 +441,9 @@ int dzg_run_second_pivot(int64_t len, double mu, const double *y, const double *
 // k_price.hip
 void dzg_launch_price(const DzgDev &d, int kernel, hipStream_t st);
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind = -1,
-                           int skip_finish = 0);
+                           int skip_finish = 0, int small = 0);
+int dzg_price_small(const DzgDev &d, int kernel);       // 1: the batch runs the fused small-k row pass
+int dzg_price_small_partials(const DzgDev &d);          // its workgroups (= ratio partials)
 int dzg_price_rows_certain(const DzgDev &d, int kernel); // the host's bounds on k prove the row-wise pass
 void dzg_launch_transpose_to_rows(const double *A, long long lda, int m, int n, double *At,
                                   long long ldt, hipStream_t st);
@@ -494,7 +498,7 @@ void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
                           unsigned long long *dbg, const double *xrecv, hipStream_t st);
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
                            unsigned long long *dbg, int only_partials, int nrz, const double *xrecv,
-                           hipStream_t st, int fold = 0);
+                           hipStream_t st, int fold = 0, int price_small = 0);
 
 // k_rowshard.hip: column sharding with the basis side sharded by rows too (opts.shard_rows)
 void dzg_launch_rs_propose(const DzgDev &d, int mode, int nrz, double *xsend, hipStream_t st);

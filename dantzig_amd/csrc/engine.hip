@@ -657,6 +657,7 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         TRY(dev_alloc(s, &d.plist, (size_t)q)); TRY(dev_alloc(s, &d.pslot, (size_t)q));
         TRY(dev_alloc(s, &d.bcode, (size_t)m)); TRY(dev_alloc(s, &d.nbcode, (size_t)q));
         TRY(dev_alloc(s, &d.pcode, (size_t)q));
+        if (!d.csc) TRY(dev_alloc(s, &d.cpos, (size_t)(d.col1 > d.col0 ? d.col1 - d.col0 : 1)));
         const size_t np = 4096;
         TRY(dev_alloc(s, &d.fpx_r, np)); TRY(dev_alloc(s, &d.fpz_r, np));
         TRY(dev_alloc(s, &d.rx_r, np)); TRY(dev_alloc(s, &d.rz_r, np));
@@ -880,14 +881,19 @@ static void enqueue_chain_iteration(dzg_solver *s, int slot)
     pf.begin(DZG_K_FTRAN);
     dzg_launch_chain_pre(d, s->chain_grid, s->chain_bar, s->chain_dbg, nullptr, st); // status, primal FTRAN + ratio, BTRAN row
     pf.end(DZG_K_FTRAN);
-    // while the batch prices row-wise for certain, k_chain_post finishes the pass itself (FOLD)
-    const int fold = s->chain_fold && dzg_price_rows_certain(d, pk);
+    // k below ~480 for the whole batch: one fused kernel prices row-wise AND finishes (dz, ratio
+    // candidates) per column tile -- no partial sums in memory, nothing to fold.  Otherwise, while
+    // the batch prices row-wise for certain, k_chain_post finishes the pass itself (FOLD)
+    const int small = dzg_price_small(d, pk);
+    const int fold = !small && s->chain_fold && dzg_price_rows_certain(d, pk);
     pf.begin(DZG_K_PRICE);
-    dzg_launch_price_fast(d, pk, st, -1, fold);
+    dzg_launch_price_fast(d, pk, st, -1, fold, small);
     pf.end(DZG_K_PRICE);
     pf.begin(DZG_K_UPDATE);
     dzg_launch_chain_post(d, s->chain_grid, s->chain_bar, s->chain_dbg, 0,
-                          fold ? s->chain_grid : price_partials_for(s, pk), nullptr, st, fold);
+                          small ? dzg_price_small_partials(d)
+                                : (fold ? s->chain_grid : price_partials_for(s, pk)),
+                          nullptr, st, fold, small);
     pf.end(DZG_K_UPDATE);
     pf.begin(DZG_K_BASIS_UPDATE);
     if (++s->since_flush >= DZG_RMAX) {

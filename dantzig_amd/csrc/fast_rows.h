@@ -207,6 +207,8 @@ struct DzgPivotArgs {
     double *W;
     long long ldw;
     int *plist, *pslot, *pcode;
+    int *cpos;         // code -> nonbasic position (nullptr: not kept)
+    int price_small;   // this iteration's pricing pass was the fused small-k row kernel (bytes accounting)
     int col0, col1;
     const long long *cptr;
     int *log_kind, *log_enter, *log_leave;
@@ -226,6 +228,7 @@ inline DzgPivotArgs dzg_pivot_args(const DzgDev &d)
     pa.bcode = d.bcode; pa.nbcode = d.nbcode;
     pa.binv = d.binv; pa.ldb = d.ldb; pa.drow = d.drow; pa.dslot = d.dslot;
     pa.W = d.W; pa.ldw = d.ldw; pa.plist = d.plist; pa.pslot = d.pslot; pa.pcode = d.pcode;
+    pa.cpos = d.cpos; pa.price_small = 0;
     pa.col0 = d.col0; pa.col1 = d.col1; pa.cptr = d.csc ? d.cptr : nullptr;
     pa.log_kind = d.log_kind; pa.log_enter = d.log_enter; pa.log_leave = d.log_leave;
     pa.log_mu = d.log_mu; pa.log_margin = d.log_margin; pa.log_cap = d.log_cap;
@@ -384,7 +387,9 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
         const double nrows = (double)c.ncompact + (ci < 0 ? 1.0 : 0.0); // (a leaving slack's own row)
         double G = ceil(((double)c.ncompact + 1.0) / 16.0);
         G = G > 32.0 ? 32.0 : G;
-        bytes += 8.0 * nrows * (double)pa.rows_ld + 16.0 * G * (double)pa.rows_ld + 12.0 * nrows +
+        // (the fused small-k kernel keeps the partial sums in LDS and reads the code -> position map)
+        bytes += 8.0 * nrows * (double)pa.rows_ld +
+                 (pa.price_small ? 4.0 * (double)(col1 - col0) : 16.0 * G * (double)pa.rows_ld) + 12.0 * nrows +
                  32.0 * (double)q;
     } else
         bytes += 8.0 * (double)m * (double)s + 8.0 * (double)m + 32.0 * (double)q;
@@ -400,6 +405,10 @@ __device__ __forceinline__ void fast_pivot_books_s(DzgCtl *ctl, const DzgCtl &c,
         if (own_j) nnz -= cptr[cj - col0 + 1] - cptr[cj - col0];
         if (own_i) nnz += cptr[ci - col0 + 1] - cptr[ci - col0];
         ctl->nb_nnz = nnz;
+    }
+    if (pa.cpos) { // column code -> nonbasic position (k_price_rows_small)
+        if (own_j) pa.cpos[cj - col0] = -1;
+        if (own_i) pa.cpos[ci - col0] = r;
     }
     if (own_j && !own_i) { // an owned structural column left the nonbasic set
         plist[idx_r] = lastpos;

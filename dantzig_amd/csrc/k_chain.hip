@@ -41,6 +41,7 @@
 // seven-launch kernels call (fast_rows.h), and argmax reductions do not depend on how candidates are
 // grouped, so a solve is bit-identical whichever form runs an iteration; the host may switch between
 // them at any poll (it does when the compact width outgrows the LDS copy of the gathered column).
+#include <chrono>
 #include "common.h"
 #include "fast_decide.h"
 #include "fast_rows.h"
@@ -884,14 +885,16 @@ void dzg_launch_chain_pre(const DzgDev &d, int grid, unsigned long long *bar,
 
 void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
                            unsigned long long *dbg, int only_partials, int nrz, const double *xrecv,
-                           hipStream_t st, int fold)
+                           hipStream_t st, int fold, int price_small)
 {
+    DzgPivotArgs pa = dzg_pivot_args(d);
+    pa.price_small = price_small;
     if (xrecv)
         hipLaunchKernelGGL(k_chain_post<true>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar,
-                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv, 0);
+                           pa, only_partials, nrz, dbg, xrecv, 0);
     else
         hipLaunchKernelGGL(k_chain_post<false>, dim3(grid), dim3(CH_THREADS), 0, st, d, bar,
-                           dzg_pivot_args(d), only_partials, nrz, dbg, xrecv, fold);
+                           pa, only_partials, nrz, dbg, xrecv, fold);
 }
 
 // ---------------------------------------------------------------------------------
@@ -899,10 +902,12 @@ void dzg_launch_chain_post(const DzgDev &d, int grid, unsigned long long *bar,
 // workgroup -- 136 KB -- fits beside it on the CU) and watches the 100 MHz clock until the time is
 // up: an exit every wave reaches.  Launched on a stream of its own.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_debug_hold(unsigned long long ticks, int *sink)
+__global__ __launch_bounds__(64) void k_debug_hold(unsigned long long ticks, int *sink, int *started)
 {
     extern __shared__ double s_hold[];
     s_hold[threadIdx.x] = 1.0;
+    // (host-visible: the host waits until every workgroup of the co-tenant holds its CU)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long spins = 0;
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && spins < (1ull << 34)) {
@@ -914,7 +919,10 @@ __global__ __launch_bounds__(64) void k_debug_hold(unsigned long long ticks, int
 
 static hipStream_t g_hold_stream = nullptr;
 static int *g_hold_sink = nullptr;
+static int *g_hold_started = nullptr; // pinned host memory
 
+// Returns once every workgroup of the co-tenant is resident (or DZG_E_DEVICE after two seconds):
+// whether it gets in the way must not depend on how the two streams' first launches race.
 extern "C" int dzg_debug_hold_cus(int32_t device, int32_t workgroups, double seconds)
 {
     if (workgroups < 1 || workgroups > 256 || !(seconds > 0.0) || seconds > 30.0) return DZG_E_ARG;
@@ -926,9 +934,17 @@ extern "C" int dzg_debug_hold_cus(int32_t device, int32_t workgroups, double sec
     if (!g_hold_stream && hipStreamCreateWithFlags(&g_hold_stream, hipStreamNonBlocking) != hipSuccess)
         return DZG_E_DEVICE;
     if (!g_hold_sink && hipMalloc(&g_hold_sink, sizeof(int)) != hipSuccess) return DZG_E_NOMEM;
+    if (!g_hold_started && hipHostMalloc(&g_hold_started, sizeof(int), hipHostMallocCoherent) != hipSuccess)
+        return DZG_E_NOMEM;
+    *(volatile int *)g_hold_started = 0;
     hipLaunchKernelGGL(k_debug_hold, dim3(workgroups), dim3(64), lds, g_hold_stream,
-                       (unsigned long long)(seconds * 1e8), g_hold_sink);
-    return hipGetLastError() == hipSuccess ? 0 : DZG_E_DEVICE;
+                       (unsigned long long)(seconds * 1e8), g_hold_sink, g_hold_started);
+    if (hipGetLastError() != hipSuccess) return DZG_E_DEVICE;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (*(volatile int *)g_hold_started < workgroups) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) return DZG_E_DEVICE;
+    }
+    return 0;
 }
 
 extern "C" int dzg_debug_hold_wait(void)

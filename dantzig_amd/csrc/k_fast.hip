@@ -529,14 +529,21 @@ __global__ __launch_bounds__(256) void k_fast_init(DzgCtl *ctl, int m, int q, in
                                                    int *pslot, int col0, int col1,
                                                    const long long *__restrict__ cptr, int *drow,
                                                    const int *__restrict__ basis, int *bcode,
-                                                   int *nbcode, int *pcode)
+                                                   int *nbcode, int *pcode, int *cpos)
 {
     // single workgroup: the structural-position list must be built in position order
     for (int r = threadIdx.x; r < m; r += blockDim.x) {
         dslot[r] = -1;
         bcode[r] = var_col[basis[r]];
     }
-    for (int k = threadIdx.x; k < q; k += blockDim.x) nbcode[k] = var_col[nonbasis[k]];
+    if (cpos)
+        for (int j = threadIdx.x; j < col1 - col0; j += blockDim.x) cpos[j] = -1;
+    __syncthreads();
+    for (int k = threadIdx.x; k < q; k += blockDim.x) {
+        const int code = var_col[nonbasis[k]];
+        nbcode[k] = code;
+        if (cpos && code >= col0 && code < col1) cpos[code - col0] = k;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int s = 0;
@@ -687,7 +694,7 @@ void dzg_launch_fast_init(const DzgDev &d, hipStream_t st)
     hipMemsetAsync(d.ag, 0, sizeof(double) * ((size_t)d.m + 2), st);
     hipLaunchKernelGGL(k_fast_init, dim3(1), dim3(256), 0, st, d.ctl, d.m, d.q, d.dslot, d.nonbasis,
                        d.var_col, d.plist, d.pslot, d.col0, d.col1, d.csc ? d.cptr : nullptr, d.drow,
-                       d.basis, d.bcode, d.nbcode, d.pcode);
+                       d.basis, d.bcode, d.nbcode, d.pcode, d.cpos);
 }
 
 void dzg_launch_fast_select_prep(const DzgDev &d, int mode, int nrz, const double *xrecv,

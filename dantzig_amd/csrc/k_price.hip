@@ -143,6 +143,25 @@ int dzg_price_rows_groups(void) { return PR_GMAX; }
 // 1: the batch being enqueued prices row-wise for certain (dense matrix, row-major copy resident, the
 // host's upper bound on k below the rule's threshold): the chain's last launch may then finish the
 // pass itself (k_chain_post, FOLD) and the finishing launch is left out
+// The fused small-k row pass (k_price_rows_small): one GPU, dense matrix with its row-major copy
+// and the code -> position map, the host's upper bound on k for the batch below DZG_PRICE_SMALL_K
+// (default 480 <= PRS_ROWS - 1; 0: never).
+static int price_small_k(void)
+{
+    static const int v = [] {
+        const char *e = std::getenv("DZG_PRICE_SMALL_K");
+        const int x = e ? std::atoi(e) : 480;
+        return x < 0 ? 0 : (x > PRS_ROWS - 1 ? PRS_ROWS - 1 : x);
+    }();
+    return v;
+}
+int dzg_price_small(const DzgDev &d, int kernel)
+{
+    return d.cpos && d.vc && d.world <= 1 && !d.rs && dzg_price_rows_certain(d, kernel) && d.k_hint < price_small_k() &&
+           (d.ldt + PRS_TILE - 1) / PRS_TILE <= 4096;
+}
+int dzg_price_small_partials(const DzgDev &d) { return (int)((d.ldt + PRS_TILE - 1) / PRS_TILE); }
+
 int dzg_price_rows_certain(const DzgDev &d, int kernel)
 {
     // (fold_k: an A/B switch, DZG_CHAIN_FOLD_K; the default is "whenever the pass is row-wise")
@@ -150,8 +169,21 @@ int dzg_price_rows_certain(const DzgDev &d, int kernel)
            d.k_hint < d.rows_T && d.k_hint < d.fold_k;
 }
 
-void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind, int skip_finish)
+void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind, int skip_finish,
+                           int small)
 {
+    if (small) { // (the caller asked dzg_price_small)
+        // (k < 127 for the whole batch: at most eight row groups, one per wave)
+        if (d.k_hint < 8 * DZG_PR_BATCH - 1)
+            hipLaunchKernelGGL(k_price_rows_small<false>, dim3(dzg_price_small_partials(d)), dim3(512), 0, st,
+                               d.ctl, d.rows_T, d.At, d.ldt, d.col1 - d.col0, d.drow, d.bcode, d.vc, d.cpos, d.q,
+                               d.nbcode, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h);
+        else
+            hipLaunchKernelGGL(k_price_rows_small<true>, dim3(dzg_price_small_partials(d)), dim3(512), 0, st,
+                               d.ctl, d.rows_T, d.At, d.ldt, d.col1 - d.col0, d.drow, d.bcode, d.vc, d.cpos, d.q,
+                               d.nbcode, d.v, d.dz, d.z, d.zbar, d.rz_r, d.rz_k, d.rz_h);
+        return;
+    }
     if (d.csc) {
         if (d.spb && d.lcnt && kernel != DZG_PRICE_SEQ) { // sparse basis: the live entries only
             if (d.q > 0)

@@ -962,6 +962,148 @@ __global__ __launch_bounds__(256) void k_price_rows(
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k_price_rows_small: the row-wise pass AND its finishing step in one launch, for the first few
+// hundred pivots of a solve (k + 1 <= PRS_ROWS for the whole batch: the host's bound, dzg_price_small).
+// A workgroup of 512 threads owns a tile of 64 consecutive COLUMNS of the row-major copy (512
+// contiguous bytes per row: a wave's load is one coalesced segment); wave w adds the row groups
+// g = w, w + 8, ... (group g = rows c = g, g + G, ... ascending, G as in k_price_rows) into LDS,
+// wave 0 then adds a column's G partial sums in group order -- exactly k_price_rows +
+// k_price_rows_finish's sums, bit for bit -- and, knowing where each column sits among the nonbasic
+// positions (cpos, kept by the pivot's books), writes dz and forms the z-side ratio candidates.
+// Unit columns and the candidates' per-workgroup reduction as in the finishing launch.  No partial
+// sums in memory, no second launch, nothing for k_chain_post to fold: three dependent trips
+// (control block | row list, coefficients, positions | rows, z, zbar).
+// grid = ceil(ldt / 64) workgroups = its count of ratio partials.
+// ---------------------------------------------------------------------------------
+// WIDE: the loads of a wave's four groups leave together (G > 8: k >= 128); otherwise one group
+// per wave and fewer registers (four workgroups per CU instead of two: config 5 has 1 024 tiles).
+#define PRS_TILE 64
+#define PRS_ROWS 512
+template <bool WIDE>
+__global__ __launch_bounds__(512) void k_price_rows_small(
+    const DzgCtl *ctl, int rows_T, const double *__restrict__ At, long long ldt, int ncols,
+    const int *__restrict__ drow, const int *__restrict__ bcode, const double *__restrict__ vc,
+    const int *__restrict__ cpos, int q, const int *__restrict__ nbcode, const double *__restrict__ v,
+    double *__restrict__ dz, const double *__restrict__ z, const double *__restrict__ zbar,
+    double *__restrict__ rz_r, int *__restrict__ rz_k, double *__restrict__ rz_h)
+{
+    __shared__ long long s_off[PRS_ROWS];
+    __shared__ double s_coef[PRS_ROWS];
+    __shared__ double s_part[PR_GMAX][PRS_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // first trip, side by side: the control block, this thread's unit-column position, this lane's
+    // column and where it sits
+    const int spos = blockIdx.x * 512 + tid;
+    int scode = 0;
+    if (spos < q) scode = nbcode[spos];
+    const long long j = (long long)blockIdx.x * PRS_TILE + lane;
+    int pos = -1;
+    if (wave == 0 && j < ncols) pos = cpos[j];
+    const int status = ctl->status, k = ctl->ncompact, lp = ctl->leave_pos;
+    const double mu = ctl->mu, tau = ctl->tau;
+    if (status != DZG_RUNNING || k >= rows_T || k >= PRS_ROWS) return;
+    // second trip: the row list and its coefficients; z, zbar of this thread's positions
+    const int lcode = lp >= 0 ? bcode[lp] : 0; // < 0: a slack leaves, row -1 - lcode carries v = 1
+    if (tid < k) {
+        s_off[tid] = (long long)drow[tid] * ldt;
+        s_coef[tid] = vc[tid];
+    }
+    double sv = 0.0, sz = 0.0, szb = 0.0, zc = 0.0, zbc = 0.0;
+    if (scode < 0) {
+        sv = v[-1 - scode];
+        sz = z[spos];
+        szb = zbar[spos];
+    }
+    if (pos >= 0) {
+        zc = z[pos];
+        zbc = zbar[pos];
+    }
+    const int nrows = k + (lcode < 0 ? 1 : 0);
+    if (tid == k && lcode < 0) {
+        s_off[k] = (long long)(-1 - lcode) * ldt;
+        s_coef[k] = 1.0;
+    }
+    int G = (k + 1 + PR_BATCH - 1) / PR_BATCH; // (as k_price_rows)
+    G = G > PR_GMAX ? PR_GMAX : G;
+    __syncthreads();
+    // third trip: the rows of this tile -- eight rows of each of the wave's (up to four) groups in
+    // flight per lane, so that a pass of k + 1 <= 512 rows is two trips whatever G is; a group's
+    // rows are still added in ascending order into the group's own accumulator
+    const double *col = At + (j < ldt ? j : 0);
+    if (WIDE) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const int rpg = (nrows + G - 1) / G; // rows of the fullest group
+        for (int r0 = 0; r0 < rpg; r0 += 8) { // block-uniform
+            double vv[4][8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int g = wave + 8 * t; // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = g + (r0 + u) * G;
+                    vv[t][u] = (g < G && c < nrows) ? __builtin_nontemporal_load(col + s_off[c]) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int g = wave + 8 * t;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = g + (r0 + u) * G;
+                    if (g < G && c < nrows) acc[t] = fma(s_coef[c], vv[t][u], acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (wave + 8 * t < G) s_part[wave + 8 * t][lane] = acc[t];
+    } else {
+        for (int g = wave; g < G; g += 8) { // wave-uniform
+            double acc = 0.0;
+            for (int c0 = g; c0 < nrows; c0 += 8 * G) {
+                double vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * G;
+                    vv[u] = c < nrows ? __builtin_nontemporal_load(col + s_off[c]) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * G;
+                    if (c < nrows) acc = fma(s_coef[c], vv[u], acc);
+                }
+            }
+            s_part[g][lane] = acc;
+        }
+    }
+    __syncthreads();
+    DzgCand2 best = dzg_cand2_none();
+    if (pos >= 0) { // (wave 0) the finishing launch's sum: the groups in order
+        double sum = 0.0;
+        for (int g = 0; g < G; ++g) sum = sum + s_part[g][lane];
+        dz[pos] = -sum;
+        price_candidate_v(best, -sum, pos, mu, tau, zc, zbc);
+    }
+    // ---- unit columns (the arithmetic of price_slack_positions)
+    if (scode < 0) {
+        const double p = 1.0 * -sv;
+        const double d = 0.0 + p;
+        dz[spos] = d;
+        price_candidate_v(best, d, spos, mu, tau, sz, szb);
+    }
+    for (int ps = spos + (int)gridDim.x * 512; ps < q; ps += (int)gridDim.x * 512) { // (never: 8 threads per column)
+        const int code = nbcode[ps];
+        if (code < 0) {
+            const double p = 1.0 * -v[-1 - code];
+            const double d = 0.0 + p;
+            dz[ps] = d;
+            price_candidate(best, d, ps, mu, tau, z, zbar);
+        }
+    }
+    price_publish(best, rz_r, rz_k, rz_h);
+}
+
 __global__ __launch_bounds__(256) void k_price_rows_finish(
     const DzgCtl *ctl, int rows_T, const double *__restrict__ part, long long ldt, int q,
     const int *__restrict__ plist, const int *__restrict__ pcode, const int *__restrict__ nbcode,
