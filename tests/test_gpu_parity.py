@@ -791,7 +791,8 @@ def _integer_fixture():
 
 
 def test_auto_follows_the_oracle_on_integer_lps(core):
-    """200 small-integer and 0/1 LPs of 200-400 rows (exact ties, 0/0 and x/0 ratios: the data on
+    """100 small-integer and 0/1 LPs of 200-400 rows (every other one of the 200 the fixture holds:
+    the suite's time budget; profiles/r02_fuzz_200_integer_lps_200_400_rows.txt has all of them) (exact ties, 0/0 and x/0 ratios: the data on
     which FAST numerics used to leave the reference's path without a signal) through
     dzg_core_solve with AUTO numerics: status, pivot count and pivot log (sha256 of the
     (kind, entering, leaving) triples) equal the committed CPU-oracle outcome on every one.
@@ -802,7 +803,7 @@ def test_auto_follows_the_oracle_on_integer_lps(core):
 
     fx = _integer_fixture()
     bad, strict = [], 0
-    for case in fx["cases"]:
+    for case in fx["cases"][::2]:  # (every other case of the fixture: the suite's time budget)
         a, b, c = make_lp(case["seed"], case["kind"], fx["min_m"], fx["max_m"])
         assert a.shape == (case["m"], case["ns"])
         lp = core.CoreLP.from_inequality_form(a, b, c)
@@ -813,7 +814,7 @@ def test_auto_follows_the_oracle_on_integer_lps(core):
             bad.append((case["seed"], r.status, case["status"], r.iterations, case["pivots"],
                         r.numerics))
     assert not bad, bad
-    assert strict > 150  # these LPs are full of ties: nearly all must have been handed to STRICT
+    assert strict > 75  # these LPs are full of ties: nearly all must have been handed to STRICT
 
 
 def test_auto_strict_resolve_runs_against_a_wall_clock_budget(core):

@@ -245,12 +245,12 @@ def test_large_sparse_model_through_surface():
 
 @pytest.mark.gpu
 def test_degenerate_transportation_model_through_surface():
-    """Integer data, heavy degeneracy (exact ties everywhere), 1270 rows: AUTO starts in FAST, meets a
-    tie within the first pivots and hands the model to STRICT (31 ms per pivot at this size)."""
+    """Integer data, heavy degeneracy (exact ties everywhere), 774 rows: AUTO starts in FAST, meets a
+    tie within the first pivots and hands the model to STRICT (some 15 ms per pivot at this size)."""
     from scipy.optimize import linprog
 
     rng = np.random.default_rng(4)
-    S, D = 30, 40
+    S, D = 24, 30
     supply = rng.integers(20, 60, S).astype(float)
     demand = rng.integers(5, 25, D).astype(float)
     cost = rng.integers(1, 20, (S, D)).astype(float)
