@@ -117,6 +117,27 @@ def test_first_pivots_are_the_cpu_oracles(core, lp_data):
     assert fast.near_ties == 0
 
 
+def test_strict_takes_fasts_pivots_deep_inside_the_solve(core, lp_data):
+    """Beyond the pivots the CPU oracle holds, the arbiter is STRICT (the reference's arithmetic on the
+    GPU) -- and STRICT from pivot 0 cannot reach the inside of a 515 000-pivot solve (0.64 s per pivot
+    here).  So FAST's STATE is handed over: after 30 000 pivots of the benchmark LP (k = 1 400) its
+    basis, x, xbar, z, zbar go to a STRICT solver (core.resumed_from), which takes 8 pivots from there
+    while FAST carries on by itself: the same pivots, mu to 1e-11.  tools/strict_windows.py does the
+    same with windows of 150 pivots down to pivot 510 000 (profiles/r04_strict_windows_8192x16384.txt)."""
+    a, b, c = lp_data
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    start, window = 30000, 8
+    with core.Solver(lp, numerics=core.FAST, poll_interval=50, log_capacity=start + window + 64) as s:
+        assert s.run(start) == "iter_limit"
+        r0 = s.result(log=False)
+        assert s.run(window) == "iter_limit"
+        fast = s.result().pivots[start:start + window]
+    assert r0.iterations == start and len(fast) == window and r0.dense_columns > 1000
+    strict = core.solve(core.resumed_from(lp, r0), numerics=core.STRICT, max_iter=window)
+    assert [(k, e, l) for k, e, l, _ in strict.pivots] == [(k, e, l) for k, e, l, _ in fast]
+    assert np.allclose([p[3] for p in strict.pivots], [p[3] for p in fast], rtol=1e-11, atol=0)
+
+
 @pytest.mark.parametrize("k", [5000, 8192])
 def test_refactorisation_of_the_headline_basis_sizes(core, lp_data, k):
     """Config 3 is named after its on-device LU refactor: a basis of 8192 rows with k structural
