@@ -137,12 +137,6 @@ void dzg_launch_transpose_to_rows(const double *A, long long lda, int m, int n, 
 }
 int dzg_price_rows_groups(void) { return PR_GMAX; }
 
-// FAST numerics: structural positions from plist, ratio-test partials for the dual step
-// need_kind >= 0 (row-sharded ranks, dense, tree / row-wise kernels only): the pass runs only in an
-// iteration of that step kind
-// 1: the batch being enqueued prices row-wise for certain (dense matrix, row-major copy resident, the
-// host's upper bound on k below the rule's threshold): the chain's last launch may then finish the
-// pass itself (k_chain_post, FOLD) and the finishing launch is left out
 // The fused small-k row pass (k_price_rows_small): one GPU, dense matrix with its row-major copy
 // and the code -> position map, the host's upper bound on k for the batch below DZG_PRICE_SMALL_K
 // (default 480 <= PRS_ROWS - 1; 0: never).
@@ -162,6 +156,9 @@ int dzg_price_small(const DzgDev &d, int kernel)
 }
 int dzg_price_small_partials(const DzgDev &d) { return (int)((d.ldt + PRS_TILE - 1) / PRS_TILE); }
 
+// 1: the batch being enqueued prices row-wise for certain (dense matrix, row-major copy resident, the
+// host's upper bound on k below the rule's threshold): the chain's last launch may then finish the
+// pass itself (k_chain_post, FOLD) and the finishing launch is left out
 int dzg_price_rows_certain(const DzgDev &d, int kernel)
 {
     // (fold_k: an A/B switch, DZG_CHAIN_FOLD_K; the default is "whenever the pass is row-wise")
@@ -169,6 +166,9 @@ int dzg_price_rows_certain(const DzgDev &d, int kernel)
            d.k_hint < d.rows_T && d.k_hint < d.fold_k;
 }
 
+// FAST numerics: structural positions from plist, ratio-test partials for the dual step
+// need_kind >= 0 (row-sharded ranks, dense, tree / row-wise kernels only): the pass runs only in an
+// iteration of that step kind
 void dzg_launch_price_fast(const DzgDev &d, int kernel, hipStream_t st, int need_kind, int skip_finish,
                            int small)
 {
