@@ -638,7 +638,17 @@ extern "C" int dzg_solver_create(const dzg_lp *lp, const dzg_opts *opts_in, dzg_
         }
         // row stride: not a multiple of a large power of two, so that the first k columns of
         // consecutive rows do not all land on the same HBM channels
-        d.ldb = ((long long)m + 15) / 16 * 16 + 32;
+        // row stride of the compact inverse: 160 doubles past a multiple of 512 (1 280 bytes past a
+        // multiple of 4 KB).  FTRAN streams 2 048 rows at once, one wave each; at k = 7 700 of m = 8 192
+        // the launch takes 102.4 us with m + 32, 110.7 with m + 64, 97.7 with m + 160 (or + 288, + 544),
+        // 101.0 with m + 1 056 (profiles/r04_ftran_row_loads_ab.txt); DZG_LDB_PAD=<doubles> for A/B
+        {
+            const long long base = ((long long)m + 15) / 16 * 16;
+            long long pad = ((160 - base % 512) % 512 + 512) % 512;
+            if (pad < 32) pad += 512;
+            if (const char *e = std::getenv("DZG_LDB_PAD")) pad = std::atoi(e) / 16 * 16;
+            d.ldb = base + pad;
+        }
         d.ldw = ((long long)m + 15) / 16 * 16 + 64;
         {
             // a row-sharded basis side keeps its own rows of Binv0 only; the kernels address rows by
