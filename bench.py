@@ -173,11 +173,15 @@ def _run_in_own_group(cmd, cwd, env, timeout, stdout=None):
         raise RuntimeError(f"{cmd[0]} exited with {rc}")
 
 
-def pmc_traffic(args) -> dict | None:
+def pmc_traffic(args, warm_k: int = 0, steps: int | None = None, warmup: int | None = None) -> dict | None:
     """HBM bytes per launch of the pricing kernel from the rocprofv3 PMC counters, collected in
     two separate child runs (FETCH_SIZE and WRITE_SIZE do not fit one pass) BEFORE this process
     touches the GPU.  Units are KiB; on gfx950 FETCH_SIZE reports exactly half the bytes of a
-    wide coalesced streaming read (MI355X_MICROARCH.md, HBM), so the fetch side is doubled."""
+    wide coalesced streaming read (MI355X_MICROARCH.md, HBM), so the fetch side is doubled.
+    warm_k > 0: the child starts from a basis of that many structural columns (the regime of the
+    `deep` / `end` blocks without the pivots that lead there: the counters see every launch)."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     import csv
     import glob
     import shutil
@@ -195,8 +199,8 @@ def pmc_traffic(args) -> dict | None:
                 # launch of the child), so that the bytes per pricing pass can stand beside the
                 # algorithmic bytes of the same passes -- both depend on k, which grows with the pivots
                 cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
-                       sys.executable, os.path.abspath(__file__), "--steps", str(args.steps),
-                       "--warmup", str(args.warmup),
+                       sys.executable, os.path.abspath(__file__), "--steps", str(steps),
+                       "--warmup", str(warmup), "--warm-k", str(warm_k),
                        "--rows", str(args.rows), "--cols", str(args.cols), "--seed", str(args.seed),
                        "--price", args.price, "--no-cpu-baseline", "--no-pmc-traffic",
                        "--no-secondary", "--no-late"]
@@ -227,8 +231,13 @@ def pmc_traffic(args) -> dict | None:
     return {"bytes_per_launch": fetch + per_pass["WRITE_SIZE"],
             "fetch_bytes_corrected": fetch, "write_bytes": per_pass["WRITE_SIZE"],
             "algorithmic_bytes_per_launch_same_pivots": same_run,
-            "note": "rocprofv3 --pmc, separate passes of the same pivots as the timed region, warm-up "
-                    "included (all kernels of a pricing pass summed); FETCH_SIZE x2 (gfx950), KiB units"}
+            "note": ("rocprofv3 --pmc, separate passes of the same pivots as the timed region, warm-up "
+                     "included (all kernels of a pricing pass summed); FETCH_SIZE x2 (gfx950), KiB units"
+                     if warm_k <= 0 else
+                     "rocprofv3 --pmc, separate passes over %d pivots from a basis of %d structural columns "
+                     "(factorised on the device: the regime of this block without the pivots that lead there; "
+                     "all kernels of a pricing pass summed); FETCH_SIZE x2 (gfx950), KiB units"
+                     % (steps + warmup, warm_k))}
 
 
 def refactor_child(args) -> int:
@@ -664,6 +673,10 @@ def main() -> int:
                     help="generator G2: this many nonzeros per column, matrix kept CSC on the device")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the column-sharded RCCL path even with one rank (rehearsal)")
+    ap.add_argument("--warm-k", type=int, default=0,
+                    help="start from a basis of this many structural columns (x = 1, z = -1; factorised on the "
+                         "device before the warm-up) instead of the slack basis: a regime of the solve without "
+                         "the pivots that lead there")
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
     ap.add_argument("--cpu-sample-pivots", type=int, default=100)
     ap.add_argument("--cpu-anchor-rows", type=int, default=0,
@@ -704,6 +717,12 @@ def main() -> int:
     traffic = None if (args.no_pmc_traffic or under_profiler()) else pmc_traffic(args)
     default_dense = args.rows == 8192 and args.cols == 16384 and args.sparse_per_col == 0 \
         and args.numerics == "fast"
+    # the same counters where the pass STREAMS: children warm-started at the compact widths of the
+    # `deep` and `end` blocks (default invocation only)
+    regime_traffic = {}
+    if traffic is not None and default_dense and not (args.no_late or args.warm_k):
+        for name, wk in (("deep", 4050), ("end", 7650)):
+            regime_traffic[name] = pmc_traffic(args, warm_k=wk, steps=200, warmup=50)
     mfma_wanted = default_dense and not (args.no_late or args.no_mfma or under_profiler())
     mfma_pmc = pmc_mfma(args, args.rows) if (mfma_wanted and not args.no_pmc_traffic) else None
 
@@ -723,7 +742,7 @@ def main() -> int:
     out = measure(args.rows, args.cols, args.seed, args.sparse_per_col, args.price, args.numerics,
                   args.steps, args.warmup, late_pivots, deep_pivots, whole,
                   mfma_block=late_pivots > 0 and not args.no_mfma,
-                  end_pivots=args.end_pivots if (whole and deep_pivots > 0) else 0)
+                  end_pivots=args.end_pivots if (whole and deep_pivots > 0) else 0, warm_k=args.warm_k)
     if "mfma" in out and mfma_wanted:
         # config 3 is named after this: the refactorisation of the FULL basis (k = m = 8192), timed
         # unprofiled, and its MFMA utilisation from the counters of the child run above
@@ -732,6 +751,10 @@ def main() -> int:
         out["mfma"]["MfmaUtil_detail"] = mfma_pmc
     out["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
     out["roofline"]["traffic_detail"] = traffic
+    for name, tr in regime_traffic.items():
+        if tr and name in out and "roofline" in out[name]:
+            out[name]["roofline"]["traffic"] = tr["bytes_per_launch"]
+            out[name]["roofline"]["traffic_detail"] = tr
     if ROWS_T is not None:
         # the pass moves 8 (k+1) n_s bytes: launch-bound while k is a few hundred, a stream later in
         # the same solve -- the fractions measured there, side by side (blocks "late" and "deep")
