@@ -513,6 +513,64 @@ __global__ __launch_bounds__(256) void k_fast_flush_mfma(const DzgCtl *ctl, int 
     }
 }
 
+// The same product with the 64 x 64 tile of Wc the four waves of a workgroup share staged through
+// LDS: fetched once per workgroup (one trip, beside the strip of U and the tile of Binv0) instead of
+// once per wave -- 40 KB from the L2 per 8 KB of Binv0 became 16.  Same operands, same order of the
+// eta steps: the same bits.
+#define FLD 72 // LDS row stride in doubles (t -> t + 1 moves 16 banks on)
+__global__ __launch_bounds__(256) void k_fast_flush_mfma_lds(const DzgCtl *ctl, int m,
+                                                             double *__restrict__ binv, long long ldb,
+                                                             const double *__restrict__ U, long long ldu,
+                                                             const double *__restrict__ Wc, long long ldw)
+{
+    __shared__ double s_w[R_ * FLD];
+    const int neta = ctl->neta, k = ctl->ncompact;
+    if (neta < R_ || k <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64;
+    const int i0 = (blockIdx.y * 4 + wave) * 16;
+    if (c0 >= k || (int)blockIdx.y * 64 >= m) return; // (workgroup-uniform: the barrier below is safe)
+    const int li = lane & 15, lk = lane >> 4;
+    // one trip: the tile of Wc (row t = wave + 4 i, column c0 + lane: 512 contiguous bytes per wave
+    // load; Wc is zero beyond the file and beyond round16(k), and its rows are ldw >= m + 64 long)
+    double wreg[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wreg[i] = Wc[(long long)(wave + 4 * i) * ldw + c0 + lane];
+    const int arow = i0 + li;
+    const int arowc = arow < m ? arow : 0;
+    double av[R_ / 4];
+#pragma unroll
+    for (int s = 0; s < R_ / 4; ++s) av[s] = U[(long long)(4 * s + lk) * ldu + arowc];
+    double4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            acc[j][g] = (row < m && col < k) ? binv[(long long)row * ldb + col] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_w[(wave + 4 * i) * FLD + lane] = wreg[i];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < R_ / 4; ++s) {
+        const double a = arow < m ? -av[s] : 0.0;
+        const int t = 4 * s + lk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, s_w[t * FLD + 16 * j + li], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = i0 + lk + 4 * g, col = c0 + 16 * j + li;
+            if (row < m && col < k) binv[(long long)row * ldb + col] = acc[j][g];
+        }
+    }
+}
+
 // kcap: the compact width the flush's grid covered (the host's bound on k for the batch, k_hint).
 // A wider inverse would have been flushed in part only: loud, not silent.
 __global__ void k_fast_flush_done(DzgCtl *ctl, int kcap)
@@ -757,8 +815,12 @@ void dzg_launch_fast_flush(const DzgDev &d, hipStream_t st)
     double *binv = d.binv + (long long)r0 * d.ldb;
     const double *U = d.U + r0;
     static const bool steps = std::getenv("DZG_FLUSH_STEPS") != nullptr; // (A/B switch, tools)
+    static const bool no_lds = std::getenv("DZG_FLUSH_NO_LDS") != nullptr; // (A/B switch, tools)
     if (rows <= 0) {
-    } else if (steps)
+    } else if (!steps && !no_lds)
+        hipLaunchKernelGGL(k_fast_flush_mfma_lds, dim3((kmax + 63) / 64, (rows + 63) / 64), dim3(256), 0, st,
+                           d.ctl, rows, binv, d.ldb, U, d.ldw, d.Wc, d.ldw);
+    else if (steps)
         hipLaunchKernelGGL(k_fast_flush_mfma<false>, dim3((kmax + 63) / 64, (rows + 63) / 64), dim3(256), 0, st,
                            d.ctl, rows, binv, d.ldb, U, d.ldw, d.Wc, d.ldw);
     else
