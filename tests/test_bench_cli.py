@@ -88,3 +88,32 @@ def test_profiler_child_is_killed_with_its_whole_process_group(tmp_path):
         time.sleep(0.1)
     else:
         raise AssertionError("the grandchild survived the timeout")
+
+
+def test_cpu_baseline_measures_the_benchmarks_own_lp_when_asked(monkeypatch):
+    """cpu_baseline: `value` is the oracle's blocked twin on real pivots of the benchmark's own LP at
+    its own size (threads stated), the literal one-core sample stays beside it; without the at-size
+    leg the value is the one-core figure carried to the benchmark size.  (Small sizes here: the
+    structure of the block, not its numbers.)"""
+    monkeypatch.setenv("OMP_NUM_THREADS", "2")
+    bench = _bench()
+    both = bench.cpu_baseline(128, 256, 1002, 10, 256, 0, (512, 1003, 3))
+    assert both["kind"] == "port" and both["cores"] == 2 and both["extrapolated"] is False
+    at = both["at_benchmark_size"]
+    assert (at["rows"], at["cols"], at["seed"], at["pivots"], at["threads"]) == (256, 512, 1003, 3, 2)
+    assert abs(both["value"] - 1.0 / at["seconds_per_pivot"]) <= 1e-12 * both["value"]
+    assert both["one_core"]["extrapolated"] is True and both["measured_rows"] == 128
+    assert "pivots_equal_the_literal_oracles" not in at  # (no committed fixture for this LP)
+    alone = bench.cpu_baseline(128, 256, 1002, 10, 256, 0, None)
+    assert alone["cores"] == 1 and alone["extrapolated"] is True and "at_benchmark_size" not in alone
+    # beyond 8192 rows a pivot of the reference algorithm takes minutes on any host: no at-size leg
+    big = bench.cpu_baseline(128, 256, 1002, 10, 32768, 0, (65536, 1005, 2))
+    assert "at_benchmark_size" not in big and big["cores"] == 1
+
+
+def test_event_stride_rides_in_the_profile_word():
+    bench = _bench()
+    from dantzig_amd import _ffi
+
+    bench.EVENT_STRIDE = 8
+    assert bench.price_profile() == (1 << _ffi.K_PRICE) | (8 << 16)
