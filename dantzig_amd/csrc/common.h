@@ -269,6 +269,37 @@ __device__ __forceinline__ double dzg_div(double a, double b)
     return q;
 }
 
+// One entry of find_first_pivot (src/simplex.rs:423-437: ybar_k > 0 makes a candidate, ratio
+// -y_k / ybar_k) joins a FAST argmax.  Entries whose ybar is zero to within FAST's rounding (tau):
+//   y not above tau either: a 0/0-like ratio -- the side is marked untrustworthy (h = +inf), as ever;
+//   y above tau: the ratio is hugely negative and never wins an argmax, but WHETHER the entry is a
+//     candidate at all is the sign of a rounding error -- and the reference's status() takes another
+//     branch when a side has no candidate (src/simplex.rs:299-303).  Such an entry stands aside as a
+//     pseudo-candidate of ratio -inf: every real candidate beats it, and a side whose best is a
+//     pseudo-candidate is treated as empty AND flagged by fast_status (found by the fuzz, seed 40037).
+__device__ __forceinline__ void dzg_first_pivot_entry(DzgCand2 &best, double y, double yb, int idx, double tau)
+{
+    const double inf = __builtin_inf();
+    const bool noise = fabs(yb) <= tau;
+    if (noise && y > tau) {
+        DzgCand2 c;
+        c.r = -inf;
+        c.k = idx;
+        c.h = -inf;
+        best = dzg_better2(best, c);
+        return;
+    }
+    if (yb > 0.0) {
+        DzgCand2 c;
+        c.r = dzg_div(-y, yb);
+        c.k = idx;
+        c.h = -inf;
+        if (c.r == c.r) best = dzg_better2(best, c);
+    }
+    if (noise) best.h = inf;
+}
+
+
 // x / y with 0 / 0 = 0 (src/simplex.rs:464-468); *ok cleared on a non-finite result.
 __device__ __forceinline__ double dzg_safe_divide(double x, double y, int *ok)
 {

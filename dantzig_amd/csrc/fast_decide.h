@@ -74,13 +74,26 @@ __device__ __forceinline__ double ratio_margin(DzgCand2 c, double tau)
 // calling kernel has nothing more to do (terminated, stopped at a near tie, budget spent);
 // otherwise `kind` is the step and the control block holds kind, mu, enter_pos / leave_pos.
 __device__ __forceinline__ bool fast_status(DzgCtl *ctl, DzgCtl &c, bool lead,
-                                            const DzgCand2 &cj, const DzgCand2 &ci, double eps,
+                                            const DzgCand2 &cj_in, const DzgCand2 &ci_in, double eps,
                                             int m, bool from_records, int &kind_out,
                                             double *mu_out = nullptr)
 {
     const double inf = __builtin_inf();
     int kind = -1, verdict = DZG_RUNNING;
     double mu = 0.0;
+    // a side whose best entry is a pseudo-candidate (dzg_first_pivot_entry: ybar zero to within
+    // rounding, y not) has no candidate FAST trusts: it is empty, and which branch of status()
+    // the reference takes there is not FAST's to say -- flagged
+    DzgCand2 cj = cj_in, ci = ci_in;
+    bool unsure = false;
+    if (cj.k >= 0 && cj.r == -inf) {
+        cj.k = -1;
+        unsure = true;
+    }
+    if (ci.k >= 0 && ci.r == -inf) {
+        ci.k = -1;
+        unsure = true;
+    }
     // margin of status(): the argmax of the side that is used, the primal-vs-dual comparison,
     // the optimality test (absolute: eps is an absolute threshold), and no untrustworthy
     // ratio on the side whose index is not used (its VALUE still enters the comparisons)
@@ -129,6 +142,7 @@ __device__ __forceinline__ bool fast_status(DzgCtl *ctl, DzgCtl &c, bool lead,
         verdict = DZG_PANIC;
         if (ci.h == inf || cj.h == inf) margin = -1.0;
     }
+    if (unsure && c.tie_tol >= 0.0) margin = -1.0;
     if (verdict == DZG_RUNNING && c.iter >= c.iter_stop) {
         if (lead) ctl->status = DZG_ITER_LIMIT;
         return false;
@@ -168,7 +182,8 @@ __device__ __forceinline__ bool fast_ratio_outcome(DzgCtl *ctl, DzgCtl &c, bool 
     if (cw.k < 0) {
         if (lead) {
             ctl->status = none_status;
-            tie_book_terminal(ctl, c, margin);
+            // (the iteration's smallest margin: a flagged status() before a clean ratio test counts)
+            tie_book_terminal(ctl, c, c.margin);
         }
         return false;
     }

@@ -785,7 +785,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
         ts.mark(slot); // primal 1 / dual 4: step lengths
     }
     // ---- update of this thread's row and column; candidates on the updated values
-    const double inf = __builtin_inf();
     DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
     if (has_row) {
         double xi = x_i, xb = xbar_i;
@@ -808,14 +807,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
                 brow[app_col] = 1.0;
             }
         }
-        if (xb > 0.0) {
-            DzgCand2 cn;
-            cn.r = dzg_div(-xi, xb);
-            cn.k = row;
-            cn.h = -inf;
-            if (cn.r == cn.r) bx = dzg_better2(bx, cn);
-        }
-        if (fabs(xb) <= tau && !(xi > tau)) bx.h = inf;
+        dzg_first_pivot_entry(bx, xi, xb, row, tau);
     }
     if (has_col) {
         double zk = z_k, zb = zbar_k;
@@ -831,14 +823,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_post(const DzgDev d, unsig
             const int code = (!only_partials && col == r) ? new_code_r : nbcode_k;
             mine = code < 0 || (code >= d.col0 && code < d.col1);
         }
-        if (mine && zb > 0.0) {
-            DzgCand2 cn;
-            cn.r = dzg_div(-zk, zb);
-            cn.k = col;
-            cn.h = -inf;
-            if (cn.r == cn.r) bz = dzg_better2(bz, cn);
-        }
-        if (mine && fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
+        if (mine) dzg_first_pivot_entry(bz, zk, zb, col, tau);
     }
     bx = chain_best(bx, r1 - r0);
     bz = chain_best(bz, q1 - q0);

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
     // first-pivot candidates (src/simplex.rs:423-437) with their competition; a denominator
     // that is zero up to rounding (ybar in [-tau, tau]) is a candidate the reference may or may
     // not have -- with any ratio -- unless its numerator makes the ratio hopelessly negative
-    const double tau = c.tau, inf = __builtin_inf();
+    const double tau = c.tau;
     DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
     if (!only_partials && rowshard) // (the rows of W_t outside this rank's share of x)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
@@ -376,14 +376,7 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
             ut[i] = (i == p ? d - 1.0 : d) * rdxp;
             wt[i] = (i == wzero) ? 0.0 : v[i];
         }
-        if (xb > 0.0) {
-            DzgCand2 c;
-            c.r = dzg_div(-xi, xb);
-            c.k = i;
-            c.h = -inf;
-            if (c.r == c.r) bx = dzg_better2(bx, c);
-        }
-        if (fabs(xb) <= tau && !(xi > tau)) bx.h = inf;
+        dzg_first_pivot_entry(bx, xi, xb, i, tau);
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < q; k += stride) {
         double zk = z[k], zb = zbar[k];
@@ -400,14 +393,7 @@ __global__ __launch_bounds__(256) void k_fast_update(DzgCtl *ctl, int only_parti
             const int code = nbcode[k];
             mine = code < 0 || (code >= col0 && code < col1);
         }
-        if (mine && zb > 0.0) {
-            DzgCand2 c;
-            c.r = dzg_div(-zk, zb);
-            c.k = k;
-            c.h = -inf;
-            if (c.r == c.r) bz = dzg_better2(bz, c);
-        }
-        if (mine && fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
+        if (mine) dzg_first_pivot_entry(bz, zk, zb, k, tau);
     }
     bx = dzg_block_best2(bx);
     bz = dzg_block_best2(bz);

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void k_sp_update(
         }
     }
     const double t = c.t, s = c.s, tbar = c.tbar, sbar = c.sbar;
-    const double tau = c.tau, inf = __builtin_inf();
+    const double tau = c.tau;
     DzgCand2 bx = dzg_cand2_none(), bz = dzg_cand2_none();
     for (int i = gid; i < m; i += stride) {
         double xi = i == gid ? x_f : x[i], xb = i == gid ? xb_f : xbar[i];
@@ -803,14 +803,7 @@ __global__ __launch_bounds__(256) void k_sp_update(
             x[i] = xi;
             xbar[i] = xb;
         }
-        if (xb > 0.0) {
-            DzgCand2 cd;
-            cd.r = dzg_div(-xi, xb);
-            cd.k = i;
-            cd.h = -inf;
-            if (cd.r == cd.r) bx = dzg_better2(bx, cd);
-        }
-        if (fabs(xb) <= tau && !(xi > tau)) bx.h = inf;
+        dzg_first_pivot_entry(bx, xi, xb, i, tau);
     }
     for (int kk = gid; kk < q; kk += stride) {
         double zk = kk == gid ? z_f : z[kk], zb = kk == gid ? zb_f : zbar[kk];
@@ -822,14 +815,7 @@ __global__ __launch_bounds__(256) void k_sp_update(
             z[kk] = zk;
             zbar[kk] = zb;
         }
-        if (zb > 0.0) {
-            DzgCand2 cd;
-            cd.r = dzg_div(-zk, zb);
-            cd.k = kk;
-            cd.h = -inf;
-            if (cd.r == cd.r) bz = dzg_better2(bz, cd);
-        }
-        if (fabs(zb) <= tau && !(zk > tau)) bz.h = inf;
+        dzg_first_pivot_entry(bz, zk, zb, kk, tau);
     }
     bx = dzg_block_best2(bx);
     bz = dzg_block_best2(bz);

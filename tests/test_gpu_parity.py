@@ -817,6 +817,35 @@ def test_auto_follows_the_oracle_on_integer_lps(core):
     assert strict > 75  # these LPs are full of ties: nearly all must have been handed to STRICT
 
 
+def test_a_side_without_a_trustworthy_candidate_is_flagged(core):
+    """Found by the fuzz (seed 40037 of tools/fuzz_parity.py, round 4): max 3 x0 + 4 x1 - 4 x2 over two
+    integer rows.  After two pivots the reference holds xbar = (0, -0.5) with x = (8, 1): no xbar is
+    positive, find_first_pivot finds nothing on the x side, and status() takes its one-sided branch --
+    no optimality test (src/simplex.rs:299-303) -- into a primal step that ends Unbounded.  FAST's xbar_0
+    is the same zero up to the sign of a rounding error; when that error is positive the entry used to
+    be a candidate (ratio -8 / 1e-17), status() took the two-sided branch and answered Optimal, with no
+    near tie flagged.  An entry whose xbar is zero to within rounding while x is not now stands aside
+    (dzg_first_pivot_entry) and a side left without a real candidate is flagged: FAST follows the
+    reference into the one-sided branch and says so."""
+    a = np.array([[-3.0, -2.0, -3.0], [1.0, -2.0, 3.0]])
+    b, c = np.array([6.0, -2.0]), np.array([-3.0, -4.0, 4.0])
+    want = ora.simplex_solve(ora.stdform_from_dense(a, b, c))
+    assert want.status == "unbounded" and want.iterations == 2
+    lp = core.CoreLP.from_inequality_form(a, b, c)
+    strict = core.solve(lp, numerics=core.STRICT)
+    assert strict.status == "unbounded" and _log(strict) == _log(want)
+    for seven in (0, 1):
+        fast = core.solve(lp, numerics=core.FAST, seven_launches=seven)
+        assert fast.status == "unbounded" and _log(fast) == _log(want), (seven, fast.status)
+        assert fast.near_ties >= 1 and fast.first_near_tie == 2  # the status() after the second pivot
+    import scipy.sparse as sp
+
+    acsc = sp.csc_matrix(a)
+    lpc = core.CoreLP.from_csc(2, acsc.indptr, acsc.indices, acsc.data, b, c)
+    fast = core.solve(lpc, numerics=core.FAST)
+    assert fast.status == "unbounded" and _log(fast) == _log(want) and fast.near_ties >= 1
+
+
 def test_auto_strict_resolve_runs_against_a_wall_clock_budget(core):
     """AUTO re-solves an LP that met a near tie in STRICT (3-57 ms per pivot): with a budget of one
     second an integer LP of 333 rows whose solve needs thousands of pivots (seed 9000 of the fixture
