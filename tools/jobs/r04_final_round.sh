@@ -1,13 +1,13 @@
 # round 4: the whole GPU suite as the driver runs it, smoke(), the default bench line, kernel stats of the driver-style command
 mkdir -p gpurun_out
 t0=$(date +%s)
-timeout -k 10 880 python -m pytest tests -m gpu -x -q --durations=12 > gpurun_out/t15_full.log 2>&1; echo "suite rc=$? wall=$(( $(date +%s) - t0 )) s"; tail -22 gpurun_out/t15_full.log
+timeout -k 10 880 python -m pytest tests -m gpu -x -q --durations=12 > gpurun_out/t17_full.log 2>&1; echo "suite rc=$? wall=$(( $(date +%s) - t0 )) s"; tail -22 gpurun_out/t17_full.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 t0=$(date +%s)
-timeout -k 10 900 python bench.py > gpurun_out/r04_bench_default_v7.json 2> gpurun_out/r04_bench_default_v7.err; echo "bench rc=$? wall=$(( $(date +%s) - t0 )) s"
+timeout -k 10 900 python bench.py > gpurun_out/r04_bench_default_v8.json 2> gpurun_out/r04_bench_default_v8.err; echo "bench rc=$? wall=$(( $(date +%s) - t0 )) s"
 python3 - <<'PY'
 import json
-d=json.load(open('gpurun_out/r04_bench_default_v7.json'))
+d=json.load(open('gpurun_out/r04_bench_default_v8.json'))
 print('value',d['value'],d['ms_per_step'],d['roofline']['kernel'],d['roofline']['frac'],d['roofline']['avg_launch_us'],d['roofline'].get('traffic'),d['roofline']['algorithmic_bytes_per_launch'])
 for k in ('late','deep','end'):
     print(k,d[k]['value'],d[k]['roofline']['frac'],d[k]['roofline']['avg_launch_us'],d[k]['kernel_us_per_pivot'])
