@@ -9,11 +9,16 @@ between barriers, continuing the same solve trajectory.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--rows M --cols NS --seed S]
                   [--price tree|seq|wave] [--no-cpu-baseline] [--no-pmc-traffic] [--no-secondary]
-                  [--no-late] [--late-pivots N]
+                  [--no-late] [--late-pivots N] [--warm-k K] [--cpu-size-pivots N]
 
 `value` is the rate of the K pivots that follow the warm-up (an almost empty basis inverse); the
-"late" block times K more pivots of the same solve after --late-pivots pivots, with the basis
-inverse grown (config.k_at_* / late.k_at_* = its dense columns) and a per-kernel-class split.
+"late", "deep" and "end" blocks time K more pivots of the same solve after 20 000, 150 000 and
+400 000 pivots, with the basis inverse grown (config.k_at_* / <block>.k_at_* = its dense columns)
+and a per-kernel-class split; "whole_solve" is the solve to optimality.  The pricing pass is timed
+with HIP events on the solver's stream around every 8th pass (roofline.launches_timed) and its HBM
+traffic counted by rocprofv3 --pmc children (the timed region's pivots; and, warm-started, the deep
+and end blocks' widths).  "cpu_baseline": the CPU oracle on this host -- real pivots of the same LP
+at the same size by its blocked twin on 16 threads, the literal one-core loop beside it.
 
 The default invocation also measures config 5 (32768 x 65536, the LP the multi-GPU target is quoted
 on) and reports it under "secondary"; `value` is always the 8192 x 16384 LP.
