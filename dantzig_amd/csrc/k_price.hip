@@ -82,11 +82,14 @@ int dzg_price_partials(int kernel)
 }
 
 // partial count of the pass dzg_launch_price_fast(d, kernel) will run
+// workgroups of the live-entry pricing pass (= its ratio partials): 1 024 -- with 2 048 the launch
+// after it reduces twice the candidates for nothing (config 4: 15 060 -> 15 870 it/s at k = 1 000,
+// 13 250 -> 13 690 at k = 4 126; 512: 15 610 / 13 580); DZG_RL_GRID for A/B
 static int rl_grid(void)
 {
     static const int g = [] {
         const char *e = std::getenv("DZG_RL_GRID");
-        const int v = e ? std::atoi(e) : DZG_PRICE_CSC_BLOCKS;
+        const int v = e ? std::atoi(e) : 1024;
         return v < 1 ? 1 : (v > DZG_PRICE_CSC_BLOCKS ? DZG_PRICE_CSC_BLOCKS : v);
     }();
     return g;
