@@ -167,7 +167,7 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
              "tree": core.PRICE_TREE}[price_name]
     # poll interval 50 divides the default warm-up and step counts: no partial batches
     solver = ShardedSolver(lp, rank, world, device=local_rank, price_kernel=price,
-                           profile=1 << _ffi.K_PRICE, poll_interval=50, replicate=replicate,
+                           profile=(1 << _ffi.K_PRICE) | (EVENT_STRIDE << 16), poll_interval=50, replicate=replicate,
                            shard_rows=shard_rows)
     try:
         del a, lp
@@ -240,10 +240,12 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
         solver.close()
     dt = float(elapsed.item())
     done = it1 - it0
+    # algorithmic bytes per pricing pass (one per pivot) over the HIP-event time of the timed passes
+    # (every EVENT_STRIDE-th iteration of a batch: an event pair costs idle GPU time, bench.py)
     d_bytes = res.price_bytes - r_warm.price_bytes
     d_ms = res.kernel_ms["price"] - r_warm.kernel_ms["price"]
     d_launch = res.kernel_launches["price"] - r_warm.kernel_launches["price"]
-    achieved = (d_bytes / 1e9) / max(d_ms / 1e3, 1e-12)
+    achieved = (d_bytes / max(done, 1) / 1e9) / max(d_ms / max(d_launch, 1) / 1e3, 1e-12) if d_launch > 0 else float("nan")
     return {
         "metric": "simplex_iterations_per_sec",
         "value": done / dt if dt > 0 else float("nan"),
@@ -280,12 +282,15 @@ def _measure_sharded(dist, torch, rows, cols, seed, price_name, steps, warmup, r
                           res.dense_columns, " (dual steps only: a primal step of a row-sharded rank "
                                              "prices inside its last phase)" if shard_rows else ""),
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": None, "avg_launch_us": 1e3 * d_ms / max(d_launch, 1),
+            "traffic": None, "avg_launch_us": 1e3 * d_ms / max(d_launch, 1), "launches_timed": d_launch,
         },
         "cpu_baseline": None,
         "phases": phases,
         "pricing_bytes_all_ranks": float(pb.item()),
     }
+
+
+EVENT_STRIDE = 8  # pricing passes per timed one (opts.profile bits 16..23), as in bench.py
 
 
 DEEP = {"rows": 32768, "cols": 65536, "seed": 1005, "warm_k": 16384, "steps": 300, "warmup": 50}
